@@ -1,0 +1,142 @@
+/*
+ * medaka_amd.h -- C ABI of the MI355X-native consensus-inference engine.
+ *
+ * This is the drop-in boundary for ONE path of nanoporetech/medaka: the network forward
+ * pass behind `model.predict_on_batch(batch)` (reference medaka/prediction.py:46 ->
+ * medaka/models.py:303-313 -> medaka/architectures/gru.py:58-72).  Everything above it
+ * (prediction.py's run_prediction loop, torch_ext.Batch, model loading) and either side of it
+ * (features.py / src/medaka_counts.c, stitch.py) is unchanged reference code.
+ *
+ * Plain pointers and sizes only: no torch / HIP types appear in any signature (a HIP stream is
+ * passed as `void*`).  All functions return 0 on success and a non-zero code on failure;
+ * `mdk_last_error()` then returns a thread-local human-readable message.  Nothing here calls
+ * `exit()` (the reference C library does, src/medaka_counts.c:203-206 -- deliberately not
+ * mirrored).
+ *
+ * There is NO CPU fallback behind this interface: if no HIP device is usable every compute
+ * entry point fails with MDK_ERR_DEVICE.
+ */
+#ifndef MEDAKA_AMD_H
+#define MEDAKA_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDK_OK 0
+#define MDK_ERR_ARG 1      /* bad argument / unsupported architecture */
+#define MDK_ERR_DEVICE 2   /* HIP runtime error (message has hipGetErrorString) */
+#define MDK_ERR_OOM 3      /* device allocation failed: lower the batch size (reference README.md:156-159) */
+
+/* Precision of the recurrent / projection contractions. */
+#define MDK_PREC_FP32 0  /* parity mode: fp16 hi+lo split operands, fp32 accumulate (<=1e-6 of fp32) */
+#define MDK_PREC_FP16 1  /* what `TorchModel.half()` selects (models.py:298-301): fp16 operands */
+
+/* Kernel family used by mdk_gru_forward*. */
+#define MDK_VARIANT_MFMA 0   /* production kernels (MFMA, LDS-resident hidden state) */
+#define MDK_VARIANT_EXACT 1  /* plain fp32 VALU kernels: slow, bit-simple, for on-device cross-checks */
+
+typedef struct mdk_gru mdk_gru;
+
+/*
+ * Architecture of reference `GRUModel.__init__` (medaka/architectures/gru.py:13-56).
+ * Supported: hidden == 128, 1 <= num_layers <= 4, bidirectional 0/1, num_features <= 256,
+ * num_classes == 5 (the reference hard-codes Linear(.., 5), gru.py:53-55).
+ */
+typedef struct {
+    int num_features;  /* 10: channels a c g t A C G T d D (src/medaka_counts.h:19-30) */
+    int hidden;        /* gru_size, 128 for every bundled consensus / variant model */
+    int num_layers;    /* 2 */
+    int bidirectional; /* 1 */
+    int num_classes;   /* 5: '*ACGT' (medaka/labels.py:342) */
+    int normalise;     /* 1: softmax over classes (gru.py:68-71); 0: logits */
+} mdk_gru_desc;
+
+/* Per-kernel device time of the last timed forward, milliseconds (hipEvent based). */
+typedef struct {
+    float h2d_ms;
+    float gi_ms[4];       /* input projection per layer */
+    float rec_ms[4];      /* recurrence per layer (both directions) -- the dominant kernel */
+    float head_ms;        /* Linear + softmax */
+    float d2h_ms;
+    float total_ms;       /* first kernel start -> last kernel end (device-resident region) */
+    int rec_launches;     /* recurrence launches in the last forward */
+    int n_layers;
+} mdk_gru_timing;
+
+/*
+ * Replaces: `ModelStoreTGZ.load_model` -> `GRUModel(...)`; `load_state_dict`; `.to(device)`
+ * (medaka/datastore.py:135-157, medaka/architectures/gru.py:46-56).
+ * `weights` holds host pointers to contiguous fp32 tensors in torch `state_dict()` order:
+ *   for layer l, for direction d in (fwd[, reverse]):
+ *       weight_ih (3H x K_l), weight_hh (3H x H), bias_ih (3H), bias_hh (3H)
+ *   then linear.weight (C x D*H), linear.bias (C);   n_weights = 4*L*D + 2.
+ * Gate row blocks are ordered r, z, n (PyTorch nn.GRU).  Weights are copied; the caller keeps
+ * ownership of its buffers.  `device` is the HIP device ordinal among the visible devices
+ * (the reference uses device 0 of the visible set, medaka/prediction.py:136-138).
+ */
+int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weights, int n_weights,
+                   int device, mdk_gru **out);
+
+/*
+ * Replaces: `TorchModel.predict_on_batch` (medaka/models.py:303-313) for CountsMatrixModel
+ * input (`batch.counts_matrix`, medaka/architectures/base_classes.py:9-11):
+ * x_host: B x T x num_features contiguous fp32 (host);  probs_host: B x T x num_classes fp32
+ * (host), fully overwritten.  Synchronous: returns when probs_host is complete.  B, T >= 0;
+ * any B (last batch is short, medaka/common.py:903-916) and any T (the un-chunked B=1 second
+ * pass, medaka/prediction.py:196-209).
+ */
+int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host);
+
+/*
+ * Same contraction with device-resident buffers (what `GRUModel.forward`, gru.py:58-72, is to
+ * `predict_on_batch`).  x_dev / probs_dev are device pointers valid on the model's device;
+ * `stream` is a hipStream_t (NULL = the model's own stream).  Asynchronous with respect to the
+ * host unless timing is enabled.
+ */
+int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
+                        void *stream);
+
+/* Replaces `TorchModel.half()` (models.py:298-301): MDK_PREC_FP32 (default) / MDK_PREC_FP16. */
+int mdk_gru_set_precision(mdk_gru *m, int precision);
+int mdk_gru_set_variant(mdk_gru *m, int variant);
+/* `normalise` attribute of GRUModel (gru.py:56,68): 1 softmax, 0 logits. */
+int mdk_gru_set_normalise(mdk_gru *m, int normalise);
+
+/* hipEvent timing of every kernel of the following forwards (adds a stream sync per forward). */
+int mdk_gru_enable_timing(mdk_gru *m, int on);
+int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);
+
+/* Device ordinal the model lives on (`TorchModel.device()`, models.py:291-296). */
+int mdk_gru_device(const mdk_gru *m);
+void mdk_gru_destroy(mdk_gru *m);
+
+/*
+ * Replaces `MajorityVoteModel.forward` (medaka/architectures/majority_vote_model.py:37-53):
+ * x_dev: n_cols x 10 fp32, probs_dev: n_cols x 5 fp32, both device pointers.
+ */
+int mdk_majority_forward_dev(const float *x_dev, long n_cols, float *probs_dev, int device,
+                             void *stream);
+int mdk_majority_forward(const float *x_host, long n_cols, float *probs_host, int device);
+
+/* Raw device helpers for hosts that do not carry their own HIP runtime binding (bench, tests). */
+int mdk_device_count(int *count);
+int mdk_device_name(int device, char *buf, size_t buflen);
+int mdk_dev_alloc(int device, size_t bytes, void **ptr);
+int mdk_dev_free(int device, void *ptr);
+int mdk_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int mdk_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int mdk_device_synchronize(int device);
+
+/* MFMA fragment-layout / subnormal self-test run on the device (used by the gpu tests). */
+int mdk_selftest_mfma(int device, float *max_abs_err, int *subnormal_preserved);
+
+const char *mdk_last_error(void);
+const char *mdk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDAKA_AMD_H */

@@ -1,0 +1,48 @@
+"""Build the HIP engine in-tree: medaka_amd/csrc/*.hip -> medaka_amd/libmedaka_amd.so (gfx950).
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmedaka_amd.so")
+SOURCES = ["api.hip"]
+HEADERS = ["common.hpp", "rec_mfma.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
+           os.path.join("..", "..", "include", "medaka_amd.h")]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile for gfx950.  Returns the path of the shared library."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-ffp-contract=off",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + list(extra_flags)
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    flags = [a for a in sys.argv[1:] if a.startswith("-")]
+    print(build(force=True, verbose=True, extra_flags=flags))

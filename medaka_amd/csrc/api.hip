@@ -1,0 +1,606 @@
+// C ABI of the MI355X consensus-inference engine (include/medaka_amd.h).
+// Host side: weight packing, workspace management, launch sequencing, hipEvent timing.
+// No CPU fallback exists here: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/medaka_amd.h"
+#include "common.hpp"
+#include "exact.hpp"
+#include "gi_proj.hpp"
+#include "head.hpp"
+#include "rec_mfma.hpp"
+
+using namespace mdk;
+
+// ------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            int code_ = (e_ == hipErrorOutOfMemory) ? MDK_ERR_OOM : MDK_ERR_DEVICE;            \
+            return fail(code_, "%s failed: %s (%s:%d)%s", #expr, hipGetErrorString(e_),        \
+                        __FILE__, __LINE__,                                                    \
+                        code_ == MDK_ERR_OOM ? " -- lower the batch size (-b)" : "");          \
+        }                                                                                      \
+    } while (0)
+
+extern "C" const char *mdk_last_error(void) { return g_err.c_str(); }
+extern "C" const char *mdk_version(void) { return "medaka_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------
+// model object
+struct LayerDev {
+    int K = 0;                    // input width of this layer
+    float *w_ih_t = nullptr;      // [D][K][384] fp32
+    float *w_hh_t = nullptr;      // [D][128][384] fp32
+    float *bias_gi = nullptr;     // [D][384]
+    float *b_hn = nullptr;        // [D][128]
+    half8 *whh_frag = nullptr;    // [D][4][6][4][2][64]
+    half8 *wih_frag = nullptr;    // [D][2][4][K/32][3][2][64] (layers >= 1)
+    float *inv_scale_rec = nullptr;  // [D]
+    float *inv_scale_gi = nullptr;   // [D]
+};
+
+struct mdk_gru {
+    mdk_gru_desc desc{};
+    int device = 0;
+    int D = 2;
+    int precision = MDK_PREC_FP32;
+    int variant = MDK_VARIANT_MFMA;
+    std::vector<LayerDev> layers;
+    float *lin_w = nullptr, *lin_b = nullptr;
+    // workspace (grown on demand)
+    float *gi = nullptr;
+    float *act[2] = {nullptr, nullptr};
+    size_t ws_rows = 0;
+    // host-API staging
+    float *x_dev = nullptr, *p_dev = nullptr;
+    size_t x_cap = 0, p_cap = 0;
+    hipStream_t stream = nullptr;
+    // timing
+    bool timing = false;
+    mdk_gru_timing last{};
+    std::vector<hipEvent_t> ev;
+};
+
+static void free_dev(void *p) { if (p) (void)hipFree(p); }
+
+extern "C" void mdk_gru_destroy(mdk_gru *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (auto &L : m->layers) {
+        free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
+        free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
+    }
+    free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
+    free_dev(m->x_dev); free_dev(m->p_dev);
+    for (auto e : m->ev) (void)hipEventDestroy(e);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+// power-of-two scale s.t. max|w| * scale <= 2^14 (fp16 max 65504), clamped
+static float pick_scale(const float *w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    int e = 0;
+    (void)std::frexp(mx, &e);         // mx = f * 2^e, f in [0.5, 1)
+    int sh = 14 - e;                  // mx * 2^sh in [2^13, 2^14)
+    sh = std::max(-10, std::min(14, sh));
+    return std::ldexp(1.0f, sh);
+}
+
+static inline void split_host(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src) {
+    HIP_TRY(hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weights,
+                              int n_weights, int device, mdk_gru **out) {
+    if (!desc || !weights || !out) return fail(MDK_ERR_ARG, "null argument");
+    *out = nullptr;
+    const int I = desc->num_features, H = desc->hidden, L = desc->num_layers;
+    const int D = desc->bidirectional ? 2 : 1, C = desc->num_classes;
+    if (H != kH) return fail(MDK_ERR_ARG, "unsupported gru_size %d (engine supports 128)", H);
+    if (L < 1 || L > 4) return fail(MDK_ERR_ARG, "unsupported num_layers %d (1..4)", L);
+    if (I < 1 || I > 256) return fail(MDK_ERR_ARG, "unsupported num_features %d (1..256)", I);
+    if (C != 5) return fail(MDK_ERR_ARG, "unsupported num_classes %d (reference Linear is fixed at 5)", C);
+    if (n_weights != 4 * L * D + 2) return fail(MDK_ERR_ARG, "expected %d weight tensors, got %d", 4 * L * D + 2, n_weights);
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) return fail(MDK_ERR_ARG, "weight tensor %d is null", i);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(MDK_ERR_DEVICE, "device %d not available (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mdk_gru *m = new mdk_gru();
+    m->desc = *desc;
+    m->device = device;
+    m->D = D;
+    m->layers.resize(L);
+    int rc = MDK_OK;
+    auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
+
+    for (int l = 0; l < L; ++l) {
+        LayerDev &Ld = m->layers[l];
+        const int K = (l == 0) ? I : D * H;
+        Ld.K = K;
+        std::vector<float> w_ih_t((size_t)D * K * kG), w_hh_t((size_t)D * kH * kG);
+        std::vector<float> bias_gi((size_t)D * kG), b_hn((size_t)D * kH);
+        std::vector<float> inv_rec(D), inv_gi(D);
+        std::vector<half8> whh_frag((size_t)D * 4 * 6 * 4 * 2 * 64);
+        const int KS = (K % 32 == 0) ? K / 32 : 0;
+        std::vector<half8> wih_frag;
+        if (l > 0) wih_frag.resize((size_t)D * 4 * KS * 6 * 2 * 64);
+        for (int d = 0; d < D; ++d) {
+            const float *w_ih = weights[4 * (l * D + d) + 0];
+            const float *w_hh = weights[4 * (l * D + d) + 1];
+            const float *b_ih = weights[4 * (l * D + d) + 2];
+            const float *b_hh = weights[4 * (l * D + d) + 3];
+            for (int j = 0; j < kG; ++j) {
+                for (int k = 0; k < K; ++k) w_ih_t[((size_t)d * K + k) * kG + j] = w_ih[(size_t)j * K + k];
+                for (int k = 0; k < kH; ++k) w_hh_t[((size_t)d * kH + k) * kG + j] = w_hh[(size_t)j * kH + k];
+                bias_gi[(size_t)d * kG + j] = b_ih[j] + (j < 2 * kH ? b_hh[j] : 0.0f);
+            }
+            for (int j = 0; j < kH; ++j) b_hn[(size_t)d * kH + j] = b_hh[2 * kH + j];
+            // recurrent B-fragments (rec_mfma.hpp): tile t6 = s*3 + gate, column n = lane&15
+            const float sw = pick_scale(w_hh, (size_t)kG * kH);
+            inv_rec[d] = 1.0f / (kActScale * sw);
+            for (int w = 0; w < 4; ++w)
+                for (int s = 0; s < 2; ++s)
+                    for (int gate = 0; gate < 3; ++gate)
+                        for (int ks = 0; ks < 4; ++ks)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int n = lane & 15, gq = lane >> 4;
+                                const int j = gate * kH + 32 * w + 16 * s + n;
+                                half8 hi, lo;
+                                for (int i = 0; i < 8; ++i) {
+                                    const int k = rec_unit_of_slot(ks, gq, i);
+                                    _Float16 a, b;
+                                    split_host(w_hh[(size_t)j * kH + k] * sw, a, b);
+                                    hi[i] = a; lo[i] = b;
+                                }
+                                const int t6 = s * 3 + gate;
+                                const size_t base = ((((size_t)(d * 4 + w) * 6 + t6) * 4 + ks) * 2) * 64 + lane;
+                                whh_frag[base] = hi;
+                                whh_frag[base + 64] = lo;
+                            }
+            if (l > 0) {
+                const float swi = pick_scale(w_ih, (size_t)kG * K);
+                inv_gi[d] = 1.0f / (kActScale * swi);
+                for (int nhalf = 0; nhalf < 2; ++nhalf)
+                    for (int w = 0; w < 4; ++w)
+                        for (int ks = 0; ks < KS; ++ks)
+                            for (int nt = 0; nt < 3; ++nt)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int col = gemm_col(nhalf, w, nt, lane & 15);
+                                    const int gq = lane >> 4;
+                                    half8 hi, lo;
+                                    for (int i = 0; i < 8; ++i) {
+                                        const int k = 32 * ks + 8 * gq + i;
+                                        _Float16 a, b;
+                                        split_host(w_ih[(size_t)col * K + k] * swi, a, b);
+                                        hi[i] = a; lo[i] = b;
+                                    }
+                                    const size_t base = (((((size_t)((d * 2 + nhalf) * 4 + w)) * KS + ks) * 3 + nt) * 2) * 64 + lane;
+                                    wih_frag[base] = hi;
+                                    wih_frag[base + 64] = lo;
+                                }
+            } else {
+                inv_gi[d] = 1.0f;
+            }
+        }
+        if ((rc = upload(&Ld.w_ih_t, w_ih_t))) return bail(rc);
+        if ((rc = upload(&Ld.w_hh_t, w_hh_t))) return bail(rc);
+        if ((rc = upload(&Ld.bias_gi, bias_gi))) return bail(rc);
+        if ((rc = upload(&Ld.b_hn, b_hn))) return bail(rc);
+        if ((rc = upload(&Ld.whh_frag, whh_frag))) return bail(rc);
+        if (l > 0 && (rc = upload(&Ld.wih_frag, wih_frag))) return bail(rc);
+        if ((rc = upload(&Ld.inv_scale_rec, inv_rec))) return bail(rc);
+        if ((rc = upload(&Ld.inv_scale_gi, inv_gi))) return bail(rc);
+    }
+    {
+        std::vector<float> lw(weights[4 * L * D], weights[4 * L * D] + (size_t)C * D * H);
+        std::vector<float> lb(weights[4 * L * D + 1], weights[4 * L * D + 1] + C);
+        if ((rc = upload(&m->lin_w, lw))) return bail(rc);
+        if ((rc = upload(&m->lin_b, lb))) return bail(rc);
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8 * 64 * 16));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 64 * 16));
+    *out = m;
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_set_precision(mdk_gru *m, int precision) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (precision != MDK_PREC_FP32 && precision != MDK_PREC_FP16) return fail(MDK_ERR_ARG, "bad precision %d", precision);
+    m->precision = precision;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_set_variant(mdk_gru *m, int variant) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (variant != MDK_VARIANT_MFMA && variant != MDK_VARIANT_EXACT) return fail(MDK_ERR_ARG, "bad variant %d", variant);
+    m->variant = variant;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_set_normalise(mdk_gru *m, int normalise) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    m->desc.normalise = normalise ? 1 : 0;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_enable_timing(mdk_gru *m, int on) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    m->timing = on != 0;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out) {
+    if (!m || !out) return fail(MDK_ERR_ARG, "null argument");
+    *out = m->last;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_device(const mdk_gru *m) { return m ? m->device : -1; }
+
+// ------------------------------------------------------------------------------------------
+// forward
+static const size_t kMaxRowsPerPass = (size_t)8 << 20;  // 8 Mi columns per pass: 24.6 GB gi + 16 GB act
+
+static int ensure_workspace(mdk_gru *m, size_t rows) {
+    if (rows <= m->ws_rows) return MDK_OK;
+    free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
+    m->gi = m->act[0] = m->act[1] = nullptr;
+    m->ws_rows = 0;
+    const size_t D = m->D;
+    HIP_TRY(hipMalloc((void **)&m->gi, D * rows * kG * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->act[0], rows * D * kH * sizeof(float)));
+    if (m->desc.num_layers > 1) HIP_TRY(hipMalloc((void **)&m->act[1], rows * D * kH * sizeof(float)));
+    m->ws_rows = rows;
+    return MDK_OK;
+}
+
+struct EvTimer {
+    mdk_gru *m;
+    hipStream_t s;
+    size_t next = 0;
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;  // slot id -> (start, stop)
+    int begin(int slot) {
+        if (!m->timing) return MDK_OK;
+        while (m->ev.size() < next + 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(m->ev[next], s));
+        spans.push_back({slot, {next, next + 1}});
+        next += 2;
+        return MDK_OK;
+    }
+    int end() {
+        if (!m->timing) return MDK_OK;
+        HIP_TRY(hipEventRecord(m->ev[spans.back().second.second], s));
+        return MDK_OK;
+    }
+};
+
+enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
+
+static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs, hipStream_t s,
+                        EvTimer &tm) {
+    const int D = m->D, L = m->desc.num_layers;
+    const long M = (long)nb * T;
+    const size_t gi_dir_stride = (size_t)M * kG;
+    const int out_stride = D * kH;
+    const int reverse_mask = (D == 2) ? 2 : 0;
+    const bool exact = (m->variant == MDK_VARIANT_EXACT);
+    int rc;
+    const float *in = x;
+    for (int l = 0; l < L; ++l) {
+        const LayerDev &Ld = m->layers[l];
+        float *outp = m->act[l & 1];
+        // ---- input projection
+        if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
+        if (exact || (l == 0 && Ld.K > 16) || (l > 0 && Ld.K != 256 && Ld.K != 128)) {
+            hipLaunchKernelGGL(k_gi_exact, dim3((unsigned)(3 * M), D), dim3(128), 0, s, in, Ld.w_ih_t,
+                               Ld.bias_gi, m->gi, M, Ld.K, gi_dir_stride);
+        } else if (l == 0) {
+            const int rpb = 64;
+            hipLaunchKernelGGL(k_gi_small<16>, dim3((unsigned)((M + rpb - 1) / rpb), D), dim3(192), 0, s,
+                               in, Ld.w_ih_t, Ld.bias_gi, m->gi, M, Ld.K, gi_dir_stride, rpb);
+        } else {
+            const unsigned grid = (unsigned)((M + kGemmRows - 1) / kGemmRows);
+            if (Ld.K == 256) {
+                const size_t lds = (size_t)2 * 8 * 8 * 64 * sizeof(half8);
+                hipLaunchKernelGGL(k_gi_gemm<8>, dim3(grid), dim3(256), lds, s, in, Ld.wih_frag,
+                                   Ld.bias_gi, m->gi, M, D, gi_dir_stride, Ld.inv_scale_gi);
+            } else {
+                const size_t lds = (size_t)2 * 8 * 4 * 64 * sizeof(half8);
+                hipLaunchKernelGGL(k_gi_gemm<4>, dim3(grid), dim3(256), lds, s, in, Ld.wih_frag,
+                                   Ld.bias_gi, m->gi, M, D, gi_dir_stride, Ld.inv_scale_gi);
+            }
+        }
+        if ((rc = tm.end())) return rc;
+        // ---- recurrence
+        if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
+        if (exact) {
+            hipLaunchKernelGGL(k_rec_exact, dim3(nb, D), dim3(128), 0, s, m->gi, Ld.w_hh_t, Ld.b_hn, outp,
+                               nb, T, out_stride, gi_dir_stride, reverse_mask);
+        } else {
+            hipLaunchKernelGGL(k_rec_mfma<4>, dim3((nb + kRecSeqs - 1) / kRecSeqs, D), dim3(256), 0, s,
+                               m->gi, Ld.whh_frag, Ld.b_hn, outp, nb, T, out_stride, gi_dir_stride,
+                               Ld.inv_scale_rec, reverse_mask);
+        }
+        if ((rc = tm.end())) return rc;
+        m->last.rec_launches++;
+        in = outp;
+    }
+    if ((rc = tm.begin(SLOT_HEAD))) return rc;
+    {
+        const long rows_per_block = 16;  // 4 waves x 4 rows
+        long blocks = (M + rows_per_block - 1) / rows_per_block;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (D == 2)
+            hipLaunchKernelGGL(k_linear_softmax<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
+                               m->lin_b, probs, M, m->desc.normalise);
+        else
+            hipLaunchKernelGGL(k_linear_softmax<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
+                               m->lin_b, probs, M, m->desc.normalise);
+    }
+    if ((rc = tm.end())) return rc;
+    HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+static int finish_timing(mdk_gru *m, EvTimer &tm, hipStream_t s) {
+    if (!m->timing) return MDK_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (auto &sp : tm.spans) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->ev[sp.second.first], m->ev[sp.second.second]));
+        const int slot = sp.first;
+        if (slot >= SLOT_GI0 && slot < SLOT_GI0 + 4) m->last.gi_ms[slot - SLOT_GI0] += ms;
+        else if (slot >= SLOT_REC0 && slot < SLOT_REC0 + 4) m->last.rec_ms[slot - SLOT_REC0] += ms;
+        else if (slot == SLOT_HEAD) m->last.head_ms += ms;
+    }
+    if (!tm.spans.empty()) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->ev[tm.spans.front().second.first],
+                                    m->ev[tm.spans.back().second.second]));
+        m->last.total_ms = ms;
+    }
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
+                                   void *stream) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
+    memset(&m->last, 0, sizeof(m->last));
+    m->last.n_layers = m->desc.num_layers;
+    if (B == 0 || T == 0) return MDK_OK;
+    if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    // windows per pass, bounded so that the workspace stays within a fixed column budget
+    size_t per_pass = std::max<size_t>(1, kMaxRowsPerPass / (size_t)T);
+    per_pass = std::min<size_t>(per_pass, (size_t)B);
+    if (per_pass >= kRecSeqs) per_pass -= per_pass % kRecSeqs;   // full recurrence tiles
+    int rc = ensure_workspace(m, per_pass * (size_t)T);
+    if (rc) return rc;
+    EvTimer tm{m, s};
+    for (size_t b0 = 0; b0 < (size_t)B; b0 += per_pass) {
+        const int nb = (int)std::min(per_pass, (size_t)B - b0);
+        rc = forward_pass(m, x_dev + b0 * T * m->desc.num_features, nb, T,
+                          probs_dev + b0 * T * m->desc.num_classes, s, tm);
+        if (rc) return rc;
+    }
+    return finish_timing(m, tm, s);
+}
+
+extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
+    if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); return MDK_OK; }
+    if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t nx = (size_t)B * T * m->desc.num_features, np = (size_t)B * T * m->desc.num_classes;
+    if (nx > m->x_cap) {
+        free_dev(m->x_dev); m->x_dev = nullptr; m->x_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->x_dev, nx * sizeof(float)));
+        m->x_cap = nx;
+    }
+    if (np > m->p_cap) {
+        free_dev(m->p_dev); m->p_dev = nullptr; m->p_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->p_dev, np * sizeof(float)));
+        m->p_cap = np;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (m->timing) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventCreate(&e2)); HIP_TRY(hipEventCreate(&e3));
+        HIP_TRY(hipEventRecord(e0, m->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(m->x_dev, x_host, nx * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (m->timing) HIP_TRY(hipEventRecord(e1, m->stream));
+    int rc = mdk_gru_forward_dev(m, m->x_dev, B, T, m->p_dev, m->stream);
+    if (rc) return rc;
+    if (m->timing) HIP_TRY(hipEventRecord(e2, m->stream));
+    HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    if (m->timing) HIP_TRY(hipEventRecord(e3, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->timing) {
+        HIP_TRY(hipEventElapsedTime(&m->last.h2d_ms, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&m->last.d2h_ms, e2, e3));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+    }
+    return MDK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// majority-vote model
+extern "C" int mdk_majority_forward_dev(const float *x_dev, long n_cols, float *probs_dev, int device,
+                                        void *stream) {
+    if (n_cols < 0) return fail(MDK_ERR_ARG, "negative n_cols");
+    if (n_cols == 0) return MDK_OK;
+    if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_majority, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x_dev, probs_dev, n_cols);
+    HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+extern "C" int mdk_majority_forward(const float *x_host, long n_cols, float *probs_host, int device) {
+    if (n_cols < 0) return fail(MDK_ERR_ARG, "negative n_cols");
+    if (n_cols == 0) return MDK_OK;
+    if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(device));
+    float *xd = nullptr, *pd = nullptr;
+    HIP_TRY(hipMalloc((void **)&xd, (size_t)n_cols * 10 * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&pd, (size_t)n_cols * 5 * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(xd); return fail(MDK_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    int rc = MDK_OK;
+    if (hipMemcpy(xd, x_host, (size_t)n_cols * 10 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(MDK_ERR_DEVICE, "H2D copy failed");
+    if (!rc) rc = mdk_majority_forward_dev(xd, n_cols, pd, device, nullptr);
+    if (!rc && hipMemcpy(probs_host, pd, (size_t)n_cols * 5 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(MDK_ERR_DEVICE, "D2H copy failed");
+    (void)hipFree(xd); (void)hipFree(pd);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// raw device helpers
+extern "C" int mdk_device_count(int *count) {
+    if (!count) return fail(MDK_ERR_ARG, "null argument");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return fail(MDK_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return MDK_OK;
+}
+extern "C" int mdk_device_name(int device, char *buf, size_t buflen) {
+    if (!buf || buflen == 0) return fail(MDK_ERR_ARG, "null argument");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MDK_OK;
+}
+extern "C" int mdk_dev_alloc(int device, size_t bytes, void **ptr) {
+    if (!ptr) return fail(MDK_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(ptr, bytes));
+    return MDK_OK;
+}
+extern "C" int mdk_dev_free(int device, void *ptr) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(ptr));
+    return MDK_OK;
+}
+extern "C" int mdk_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return MDK_OK;
+}
+extern "C" int mdk_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return MDK_OK;
+}
+extern "C" int mdk_device_synchronize(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return MDK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA self-test: D = A(16x32) B(32x16) with the fragment layout the kernels assume, on
+// asymmetric integer data (exact in fp16/fp32), plus an fp16-subnormal operand probe.
+__global__ void k_selftest(const _Float16 *A /*[16][32]*/, const _Float16 *Bm /*[32][16]*/,
+                           float *Dm /*[16][16]*/) {
+    const int lane = threadIdx.x;
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        const int k = (lane >> 4) * 8 + i;
+        a[i] = A[(lane & 15) * 32 + k];
+        b[i] = Bm[k * 16 + (lane & 15)];
+    }
+    floatx4 c = {0.f, 0.f, 0.f, 0.f};
+    c = mfma16(a, b, c);
+    for (int r = 0; r < 4; ++r) Dm[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = c[r];
+}
+
+extern "C" int mdk_selftest_mfma(int device, float *max_abs_err, int *subnormal_preserved) {
+    if (!max_abs_err || !subnormal_preserved) return fail(MDK_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<_Float16> A(16 * 32), Bm(32 * 16);
+    std::vector<float> ref(256, 0.f), got(256);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int m_ = 0; m_ < 16; ++m_)
+            for (int k = 0; k < 32; ++k) A[m_ * 32 + k] = (_Float16)(float)((m_ * 7 + k * 3) % 11 - 5);
+        for (int k = 0; k < 32; ++k)
+            for (int n = 0; n < 16; ++n) Bm[k * 16 + n] = (_Float16)(float)((k * 5 + n * 2 + k * n) % 13 - 6);
+        if (pass == 1) {
+            // subnormal probe: A[0][0] = 2^-20 (fp16 subnormal), B[0][0] = 1024, rest of row/col 0 zero
+            for (int k = 0; k < 32; ++k) { A[k] = (_Float16)0.f; Bm[k * 16] = (_Float16)0.f; }
+            A[0] = (_Float16)9.5367431640625e-07f;
+            Bm[0] = (_Float16)1024.f;
+        }
+        for (int m_ = 0; m_ < 16; ++m_)
+            for (int n = 0; n < 16; ++n) {
+                float acc = 0.f;
+                for (int k = 0; k < 32; ++k) acc += (float)A[m_ * 32 + k] * (float)Bm[k * 16 + n];
+                ref[m_ * 16 + n] = acc;
+            }
+        _Float16 *dA = nullptr, *dB = nullptr;
+        float *dD = nullptr;
+        HIP_TRY(hipMalloc((void **)&dA, A.size() * 2));
+        HIP_TRY(hipMalloc((void **)&dB, Bm.size() * 2));
+        HIP_TRY(hipMalloc((void **)&dD, 256 * 4));
+        HIP_TRY(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dB, Bm.data(), Bm.size() * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, nullptr, dA, dB, dD);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(got.data(), dD, 256 * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+        if (pass == 0) {
+            float e = 0.f;
+            for (int i = 0; i < 256; ++i) e = std::max(e, std::fabs(got[i] - ref[i]));
+            *max_abs_err = e;
+        } else {
+            *subnormal_preserved = (std::fabs(got[0] - ref[0]) <= 1e-6f * std::fabs(ref[0])) ? 1 : 0;
+        }
+    }
+    return MDK_OK;
+}

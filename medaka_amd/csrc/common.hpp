@@ -1,0 +1,53 @@
+// Shared device helpers for the medaka_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mdk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kH = 128;        // GRU hidden size per direction (gru.py:16, every bundled model)
+constexpr int kG = 3 * kH;     // gate rows r,z,n
+constexpr int kWave = 64;      // CDNA wavefront
+
+// Operand pre-scaling of the fp16 hi+lo split (DESIGN.md "fp16x2 split"): activations are
+// multiplied by 2^10 before the split so that the low halves stay in fp16's normal range;
+// weights by a per-matrix power of two chosen at load time.
+constexpr float kActScale = 1024.0f;
+
+// D = A(16x32) * B(32x16) + C on the matrix core, fp16 operands, fp32 accumulate.
+// Lane l holds A[row = l&15][k-slot (l>>4)*8 + i], B[k-slot (l>>4)*8 + i][col = l&15],
+// D[row = 4*(l>>4) + r][col = l&15].  Which physical k a (lane-group, i) slot stands for is
+// free as long as A and B agree -- the kernels exploit that (see rec_mfma.hpp).
+__device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// exp2/rcp based logistic and tanh: ~2 ulp, error << 1e-6 absolute on (0,1)/(-1,1)
+__device__ __forceinline__ float fast_exp(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    // 1 - 2/(e^{2x}+1): saturates correctly for |x| large (exp -> inf / 0)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp(2.0f * x));
+}
+
+// split x (already multiplied by the operand scale) into fp16 hi + fp16 lo, hi+lo ~ x to 2^-22
+__device__ __forceinline__ void split_f16(float xs, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for global loads/stores
+// in flight (the gi prefetch ring and the h stores must stay in flight across steps).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+}  // namespace mdk

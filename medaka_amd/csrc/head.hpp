@@ -1,0 +1,102 @@
+// Classifier head and the small element-wise models.
+//   k_linear_softmax : nn.Linear(D*H -> 5) + softmax(dim=-1)      (reference gru.py:67-71)
+//   k_majority       : MajorityVoteModel.forward                   (majority_vote_model.py:37-53)
+// Both are HBM-streaming kernels: one 1 KB row in, 20 B out.
+#pragma once
+#include "common.hpp"
+
+namespace mdk {
+
+// 16 lanes share one row: lane j holds float4 chunks j, j+16, j+32, j+48 of the row, the five
+// partial dot products are xor-reduced over the 16 lanes, lanes 0..4 each write one class.
+template <int NCH>   // row width = 64 * NCH floats  (NCH = 4 for bidirectional H=128)
+__global__ __launch_bounds__(256) void k_linear_softmax(
+    const float *__restrict__ hin,    // [M][64*NCH]
+    const float *__restrict__ lin_w,  // [5][64*NCH]
+    const float *__restrict__ lin_b,  // [5]
+    float *__restrict__ probs,        // [M][5]
+    long M, int normalise)
+{
+    constexpr int W = 64 * NCH;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15;
+    const int rsub = lane >> 4;
+    float4 wv[5][NCH];
+#pragma unroll
+    for (int cl = 0; cl < 5; ++cl)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            wv[cl][ch] = *reinterpret_cast<const float4 *>(lin_w + cl * W + (ch * 16 + sub) * 4);
+    float bv[5];
+#pragma unroll
+    for (int cl = 0; cl < 5; ++cl) bv[cl] = lin_b[cl];
+
+    const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long n_waves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long r4 = wave_global * 4; r4 < M; r4 += n_waves * 4) {
+        const long row = r4 + rsub;
+        const bool ok = row < M;
+        const float *hr = hin + (ok ? row : (M - 1)) * W;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const float4 v = *reinterpret_cast<const float4 *>(hr + (ch * 16 + sub) * 4);
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) {
+                acc[cl] = fmaf(v.x, wv[cl][ch].x, acc[cl]);
+                acc[cl] = fmaf(v.y, wv[cl][ch].y, acc[cl]);
+                acc[cl] = fmaf(v.z, wv[cl][ch].z, acc[cl]);
+                acc[cl] = fmaf(v.w, wv[cl][ch].w, acc[cl]);
+            }
+        }
+#pragma unroll
+        for (int cl = 0; cl < 5; ++cl) {
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) acc[cl] += __shfl_xor(acc[cl], off, 16);
+            acc[cl] += bv[cl];
+        }
+        float res[5];
+        if (normalise) {
+            float mx = acc[0];
+#pragma unroll
+            for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, acc[cl]);
+            float sum = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) { res[cl] = __expf(acc[cl] - mx); sum += res[cl]; }
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) res[cl] = res[cl] / sum;
+        } else {
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) res[cl] = acc[cl];
+        }
+        if (ok && sub < 5) {
+            float v = res[0];
+            v = sub == 1 ? res[1] : v;
+            v = sub == 2 ? res[2] : v;
+            v = sub == 3 ? res[3] : v;
+            v = sub == 4 ? res[4] : v;
+            probs[row * 5 + sub] = v;
+        }
+    }
+}
+
+// channels a c g t A C G T d D -> classes [d+D, a+A, c+C, g+G, t+T]; class 0 += 1 - sum
+__global__ __launch_bounds__(256) void k_majority(const float *__restrict__ x,
+                                                  float *__restrict__ probs, long n_cols)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cols) return;
+    const float *r = x + i * 10;
+    float p[5];
+    p[0] = r[8] + r[9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[1 + c] = r[c] + r[4 + c];
+    float s = p[0];
+#pragma unroll
+    for (int c = 1; c < 5; ++c) s += p[c];
+    p[0] += 1.0f - s;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) probs[i * 5 + c] = p[c];
+}
+
+}  // namespace mdk

@@ -1,0 +1,160 @@
+"""Thin object wrapper over the C ABI (include/medaka_amd.h): one `GruEngine` = one `mdk_gru*`.
+
+This is the layer `models.HipGRUModel` (the drop-in for reference
+`medaka.architectures.GRUModel`) sits on; tests and bench.py also drive it directly.
+"""
+import ctypes
+
+import numpy as np
+
+from medaka_amd import lib as _lib
+
+
+def state_keys(n_layers=2, bidirectional=True):
+    """torch state_dict key order of reference GRUModel (medaka/architectures/gru.py:46-55)."""
+    keys = []
+    for layer in range(n_layers):
+        for suffix in ([""] + (["_reverse"] if bidirectional else [])):
+            for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                keys.append(f"gru.{name}_l{layer}{suffix}")
+    keys += ["linear.weight", "linear.bias"]
+    return keys
+
+
+class DeviceBuffer:
+    """Raw device allocation through the C ABI (for hosts without a HIP binding of their own)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device = device
+        self.nbytes = int(nbytes)
+        self.ptr = ctypes.c_void_p()
+        _lib.check(_lib.load().mdk_dev_alloc(device, max(self.nbytes, 1), ctypes.byref(self.ptr)),
+                   "mdk_dev_alloc")
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _lib.check(_lib.load().mdk_memcpy_h2d(self.device, self.ptr, arr.ctypes.data, arr.nbytes),
+                   "mdk_memcpy_h2d")
+
+    def download(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _lib.check(_lib.load().mdk_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes),
+                   "mdk_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.load().mdk_dev_free(self.device, self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GruEngine:
+    """MI355X bi-GRU + Linear + softmax forward (reference gru.py:58-72) behind the C ABI."""
+
+    def __init__(self, state, num_features=10, gru_size=128, n_layers=2, bidirectional=True,
+                 num_classes=5, normalise=True, device=0):
+        self._h = ctypes.c_void_p()
+        L = _lib.load()
+        keys = state_keys(n_layers, bidirectional)
+        missing = [k for k in keys if k not in state]
+        if missing:
+            raise KeyError(f"state is missing {missing}")
+        arrs = [np.ascontiguousarray(np.asarray(state[k], dtype=np.float32)) for k in keys]
+        D = 2 if bidirectional else 1
+        for li in range(n_layers):
+            kin = num_features if li == 0 else D * gru_size
+            for di in range(D):
+                w_ih, w_hh, b_ih, b_hh = arrs[4 * (li * D + di):4 * (li * D + di) + 4]
+                for a, shp in ((w_ih, (3 * gru_size, kin)), (w_hh, (3 * gru_size, gru_size)),
+                               (b_ih, (3 * gru_size,)), (b_hh, (3 * gru_size,))):
+                    if a.shape != shp:
+                        raise ValueError(f"weight shape {a.shape} != expected {shp}")
+        if arrs[-2].shape != (num_classes, D * gru_size) or arrs[-1].shape != (num_classes,):
+            raise ValueError("linear weight/bias shape mismatch")
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        desc = _lib.GruDesc(num_features, gru_size, n_layers, int(bidirectional), num_classes,
+                            int(normalise))
+        _lib.check(L.mdk_gru_create(ctypes.byref(desc), ptrs, len(arrs), device,
+                                    ctypes.byref(self._h)), "mdk_gru_create")
+        self.num_features, self.num_classes, self.device = num_features, num_classes, device
+
+    # -- configuration
+    def set_precision(self, half):
+        _lib.check(_lib.load().mdk_gru_set_precision(self._h, 1 if half else 0), "mdk_gru_set_precision")
+
+    def set_variant(self, exact):
+        _lib.check(_lib.load().mdk_gru_set_variant(self._h, 1 if exact else 0), "mdk_gru_set_variant")
+
+    def set_normalise(self, normalise):
+        _lib.check(_lib.load().mdk_gru_set_normalise(self._h, int(bool(normalise))), "mdk_gru_set_normalise")
+
+    def enable_timing(self, on=True):
+        _lib.check(_lib.load().mdk_gru_enable_timing(self._h, int(on)), "mdk_gru_enable_timing")
+
+    def timing(self):
+        t = _lib.GruTiming()
+        _lib.check(_lib.load().mdk_gru_get_timing(self._h, ctypes.byref(t)), "mdk_gru_get_timing")
+        n = t.n_layers
+        return {"h2d_ms": t.h2d_ms, "gi_ms": list(t.gi_ms)[:n], "rec_ms": list(t.rec_ms)[:n],
+                "head_ms": t.head_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms,
+                "rec_launches": t.rec_launches}
+
+    # -- compute
+    def forward_host(self, x, out=None):
+        """x: (B,T,F) float32 host array -> (B,T,C) float32 host array (synchronous)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[2] != self.num_features:
+            raise ValueError(f"expected (B, T, {self.num_features}) input, got {x.shape}")
+        B, T, _ = x.shape
+        if out is None:
+            out = np.empty((B, T, self.num_classes), dtype=np.float32)
+        _lib.check(_lib.load().mdk_gru_forward(self._h, x.ctypes.data, B, T, out.ctypes.data),
+                   "mdk_gru_forward")
+        return out
+
+    def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
+        """Raw-pointer forward: host pointers (`host=True`) or device pointers + hipStream_t."""
+        L = _lib.load()
+        if host:
+            _lib.check(L.mdk_gru_forward(self._h, x_ptr, B, T, out_ptr), "mdk_gru_forward")
+        else:
+            _lib.check(L.mdk_gru_forward_dev(self._h, x_ptr, B, T, out_ptr, stream),
+                       "mdk_gru_forward_dev")
+
+    def close(self):
+        if self._h:
+            _lib.load().mdk_gru_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def majority_forward_host(x, device=0):
+    """MajorityVoteModel.forward on the device (reference majority_vote_model.py:37-53)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.shape[-1] != 10:
+        raise ValueError("majority vote expects 10 count channels")
+    out = np.empty(x.shape[:-1] + (5,), dtype=np.float32)
+    _lib.check(_lib.load().mdk_majority_forward(x.ctypes.data, x.size // 10, out.ctypes.data, device),
+               "mdk_majority_forward")
+    return out
+
+
+def selftest_mfma(device=0):
+    err = ctypes.c_float(-1.0)
+    sub = ctypes.c_int(-1)
+    _lib.check(_lib.load().mdk_selftest_mfma(device, ctypes.byref(err), ctypes.byref(sub)),
+               "mdk_selftest_mfma")
+    return err.value, bool(sub.value)

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/medaka_amd.h (libmedaka_amd.so, built in-tree).
+
+There is no Python or CPU fallback: if the shared library is missing or does not export the
+full ABI, importing the engine raises.  ctypes releases the GIL around every call, which the
+reference's threaded DataLoader relies on (reference medaka/prediction.py:268-279 runs loader,
+batcher and HDF-writer threads next to `model.predict_on_batch`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmedaka_amd.so")
+
+MDK_OK, MDK_ERR_ARG, MDK_ERR_DEVICE, MDK_ERR_OOM = 0, 1, 2, 3
+MDK_PREC_FP32, MDK_PREC_FP16 = 0, 1
+MDK_VARIANT_MFMA, MDK_VARIANT_EXACT = 0, 1
+
+
+class GruDesc(ctypes.Structure):
+    _fields_ = [("num_features", ctypes.c_int), ("hidden", ctypes.c_int),
+                ("num_layers", ctypes.c_int), ("bidirectional", ctypes.c_int),
+                ("num_classes", ctypes.c_int), ("normalise", ctypes.c_int)]
+
+
+class GruTiming(ctypes.Structure):
+    _fields_ = [("h2d_ms", ctypes.c_float), ("gi_ms", ctypes.c_float * 4),
+                ("rec_ms", ctypes.c_float * 4), ("head_ms", ctypes.c_float),
+                ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("rec_launches", ctypes.c_int), ("n_layers", ctypes.c_int)]
+
+
+# every symbol include/medaka_amd.h declares: (restype, argtypes)
+_vp, _i, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+ABI = {
+    "mdk_gru_create": (_i, [ctypes.POINTER(GruDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),
+    "mdk_gru_forward": (_i, [_vp, _vp, _i, _i, _vp]),
+    "mdk_gru_forward_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mdk_gru_set_precision": (_i, [_vp, _i]),
+    "mdk_gru_set_variant": (_i, [_vp, _i]),
+    "mdk_gru_set_normalise": (_i, [_vp, _i]),
+    "mdk_gru_enable_timing": (_i, [_vp, _i]),
+    "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
+    "mdk_gru_device": (_i, [_vp]),
+    "mdk_gru_destroy": (None, [_vp]),
+    "mdk_majority_forward_dev": (_i, [_vp, _l, _vp, _i, _vp]),
+    "mdk_majority_forward": (_i, [_vp, _l, _vp, _i]),
+    "mdk_device_count": (_i, [ctypes.POINTER(_i)]),
+    "mdk_device_name": (_i, [_i, ctypes.c_char_p, _sz]),
+    "mdk_dev_alloc": (_i, [_i, _sz, ctypes.POINTER(_vp)]),
+    "mdk_dev_free": (_i, [_i, _vp]),
+    "mdk_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
+    "mdk_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
+    "mdk_device_synchronize": (_i, [_i]),
+    "mdk_selftest_mfma": (_i, [_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+    "mdk_last_error": (ctypes.c_char_p, []),
+    "mdk_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call failed (reference convention: exceptions in Python)."""
+
+
+def load():
+    """dlopen libmedaka_amd.so and type every ABI entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X engine is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; import it first so that one HIP runtime is shared
+    # (device pointers and streams of torch tensors are then valid inside the engine).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in ABI.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().mdk_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc, what):
+    if rc != MDK_OK:
+        kind = {MDK_ERR_ARG: "bad argument", MDK_ERR_DEVICE: "device error",
+                MDK_ERR_OOM: "out of device memory"}.get(rc, f"error {rc}")
+        raise EngineError(f"{what}: {kind}: {last_error()}")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().mdk_device_count(ctypes.byref(n))
+    return n.value if rc == MDK_OK else 0
+
+
+def device_name(device=0):
+    buf = ctypes.create_string_buffer(256)
+    check(load().mdk_device_name(device, buf, 256), "mdk_device_name")
+    return buf.value.decode()

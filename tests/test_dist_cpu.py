@@ -1,0 +1,40 @@
+"""N>1 path on CPU: two gloo ranks run the bench's sharding + barrier + max-over-ranks timing."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, os.environ["MDK_ROOT"])
+from medaka_amd import dist, sharding
+ranks = dist.Ranks(backend="gloo")
+lo, hi = sharding.shard_windows(11, ranks.world, ranks.rank)
+calls = []
+def step():
+    calls.append(1)
+    time.sleep(0.01 * (ranks.rank + 1))      # rank 1 is slower: max must pick it
+elapsed_max, mine = dist.timed_steps(ranks, step, lambda: None, steps=3, warmup=1)
+total = ranks.sum_over_ranks(hi - lo)
+if ranks.rank == 0:
+    print(json.dumps({"max": elapsed_max, "mine": mine, "calls": len(calls), "total": total,
+                      "world": ranks.world, "lo_hi": [lo, hi]}))
+ranks.close()
+"""
+
+
+def test_two_rank_gloo_timing(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MDK_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["world"] == 2 and r["calls"] == 4 and r["total"] == 11 and r["lo_hi"] == [0, 6]
+    assert r["max"] >= 0.055          # slow rank: 3 * 0.02 s
+    assert r["mine"] < r["max"]       # rank 0 is the fast one

@@ -1,0 +1,145 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared
+symbol, the reference-interface mirrors behave like the reference, sharding, synthetic data."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from medaka_amd import engine, lib, models, sharding, synth
+from medaka_amd.torch_ext import Batch
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "medaka_amd.h")).read()
+    declared = set(re.findall(r"\b(mdk_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mdk_gru_timing"}
+    assert len(declared) >= 20
+    L = lib.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/medaka_amd.h but not exported"
+        assert name in lib.ABI, f"{name} missing from the ctypes ABI table"
+    assert set(lib.ABI) <= declared
+
+
+def test_version_and_error_string():
+    L = lib.load()
+    assert b"gfx950" in L.mdk_version()
+    assert isinstance(lib.last_error(), str)
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a HIP device the engine must fail loudly, never compute on the host."""
+    if lib.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    state = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_init.npz")))
+    with pytest.raises(lib.EngineError):
+        engine.GruEngine(state)
+    m = models.GRUModel()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.predict_on_batch(Batch(counts_matrix=torch.zeros(1, 4, 10)))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        models.MajorityVoteModel().predict_on_batch(Batch(counts_matrix=torch.zeros(1, 4, 10)))
+
+
+def test_engine_rejects_bad_weights():
+    state = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_init.npz")))
+    bad = dict(state)
+    bad["gru.weight_hh_l0"] = bad["gru.weight_hh_l0"][:, :64]
+    with pytest.raises(ValueError):
+        engine.GruEngine(bad)
+    missing = {k: v for k, v in state.items() if k != "linear.bias"}
+    with pytest.raises(KeyError):
+        engine.GruEngine(missing)
+
+
+def test_grumodel_mirrors_reference_interface():
+    m = models.GRUModel(num_features=10, num_classes=5, gru_size=128)
+    # state_dict keys are the stock nn.GRU / nn.Linear names
+    assert list(m.state_dict().keys()) == engine.state_keys(2, True)
+    assert m.state_dict()["gru.weight_ih_l1_reverse"].shape == (384, 256)
+    d = m.to_dict()
+    assert d["type"] == "GRUModel"
+    assert d["kwargs"] == dict(num_features=10, num_classes=5, gru_size=128, n_layers=2,
+                               bidirectional=True, time_steps=None, classify_activation=None)
+    m2 = models.model_from_dict(d)
+    assert isinstance(m2, models.GRUModel)
+    assert m.device() == torch.device("cpu")
+    assert m.normalise is True and m.half_precision is False
+    m.half()
+    assert m.half_precision is True and m.gru.weight_hh_l0.dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        m.process_batch(None, None)
+    with pytest.raises(ValueError):
+        models.model_from_dict({"type": "LatentSpaceLSTM", "kwargs": {}})
+    with pytest.warns(UserWarning):
+        models.GRUModel(time_steps=100)
+
+
+def test_feature_encoder_compatibility():
+    class CountsFeatureEncoder: pass
+    class ReadAlignmentFeatureEncoder: pass
+    class Sub(CountsFeatureEncoder): pass
+    class Other: pass
+    m = models.GRUModel()
+    m.check_feature_encoder_compatibility(CountsFeatureEncoder())
+    m.check_feature_encoder_compatibility(ReadAlignmentFeatureEncoder())
+    m.check_feature_encoder_compatibility(Sub())
+    with pytest.raises(ValueError):
+        m.check_feature_encoder_compatibility(Other())
+
+
+def test_batch_collate_counts_and_read_level():
+    class S:
+        def __init__(self, f, labels=None):
+            self.features, self.labels = f, labels
+    rng = np.random.default_rng(0)
+    samples = [S(rng.random((7, 10)).astype(np.float64), np.arange(7)) for _ in range(3)]
+    b = Batch.collate(samples)
+    assert b.counts_matrix.shape == (3, 7, 10) and b.counts_matrix.dtype == torch.float32
+    assert b.labels.shape == (3, 7) and b.read_level_features is None
+    assert b.features is b.counts_matrix and b.majority_vote_probs is None
+    rl = [S(rng.integers(0, 5, (6, d, 4)).astype(np.uint8)) for d in (3, 5)]
+    b = Batch.collate(rl)
+    assert b.read_level_features.shape == (2, 6, 5, 4) and b.read_level_features.dtype == torch.uint8
+    assert int(b.read_level_features[0, :, 3:, :].sum()) == 0   # zero padded to max depth
+    with pytest.raises(ValueError):
+        Batch.collate([S(np.zeros(4))])
+
+
+def test_sharding_lpt_and_split():
+    contigs = [("chr1", 250_000_000), ("chr2", 40_000_000), ("chr3", 30_000_000), ("chrM", 16_569)]
+    shards = sharding.shard_regions(contigs, 8)
+    assert len(shards) == 8 and all(len(s) > 0 for s in shards)
+    load = [sum(r.end - r.start for r in s) for s in shards]
+    assert max(load) <= 1.25 * (sum(load) / 8)
+    # chr1 pieces overlap by chunk_ovlp and cover the contig, cut on multiples of bam_chunk
+    pieces = sorted([r for s in shards for r in s if r.ref_name == "chr1"], key=lambda r: r.start)
+    assert pieces[0].start == 0 and pieces[-1].end == 250_000_000
+    for a, b in zip(pieces, pieces[1:]):
+        assert a.end - b.start == 1000
+        assert (a.end - a.start) % 1_000_000 == 0
+    # whole small contigs are never cut
+    assert sum(1 for s in shards for r in s if r.ref_name == "chrM") == 1
+    one = sharding.shard_regions(contigs, 1)
+    assert [r.ref_name for r in one[0]] == ["chr1", "chr2", "chr3", "chrM"]
+    assert sharding.region_str(one[0][0]) == "chr1:0-250000000"
+    lo_hi = [sharding.shard_windows(203, 8, r) for r in range(8)]
+    assert lo_hi[0][0] == 0 and lo_hi[-1][1] == 203
+    assert all(a[1] == b[0] for a, b in zip(lo_hi, lo_hi[1:]))
+    assert sharding.shard_regions([], 4) == [[], [], [], []]
+
+
+def test_synthetic_counts_contract():
+    x, y = synth.counts_windows(3, 2000, depth=60, seed=5, return_labels=True)
+    assert x.shape == (3, 2000, 10) and x.dtype == np.float32 and y.shape == (3, 2000)
+    assert x.min() >= 0 and np.isfinite(x).all()
+    rows = x.sum(-1)
+    assert rows.max() <= 1 + 1e-5                  # counts / depth of the parent major column
+    major = np.abs(rows - 1) < 1e-5                # major columns sum to 1
+    assert 0.5 < major.mean() < 0.8                # ~30-45 % minor (insertion) columns
+    assert set(np.unique(y)) == {0, 1, 2, 3, 4}
+    x2 = synth.counts_windows(3, 2000, depth=60, seed=5)
+    assert np.array_equal(x, x2)                   # seeded

@@ -1,0 +1,203 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+  (a) committed goldens produced by the UNMODIFIED reference (tests/golden/),
+  (b) the CPU oracle on the same seeded inputs,
+  (c) size-independent properties at BASELINE.json's full batch (200 x 10000).
+Tolerance (BASELINE.json north_star): per-position probabilities <= 1e-4 absolute in fp32 and
+identical argmax.  We assert 2e-5, five times tighter."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import weight_set
+from medaka_amd import engine, integration, lib, models, synth
+from medaka_amd.torch_ext import Batch
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def engines(gold):
+    cache = {}
+
+    def get(wname, exact=False):
+        key = (wname, exact)
+        if key not in cache:
+            e = engine.GruEngine(weight_set(gold, wname))
+            e.set_variant(exact)
+            cache[key] = e
+        return cache[key]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def _check(out, ref, tol=TOL, what=""):
+    assert out.shape == ref.shape, what
+    assert np.isfinite(out).all(), what
+    err = np.abs(out - ref).max() if out.size else 0.0
+    assert err <= tol, f"{what}: max|dp| = {err:.3e}"
+    # argmax identity wherever the reference itself separates top-2 by more than the tolerance
+    srt = np.sort(ref, -1)
+    clear = (srt[..., -1] - srt[..., -2]) > 2 * tol
+    assert (out.argmax(-1) == ref.argmax(-1))[clear].all(), what
+
+
+def test_mfma_fragment_layout_selftest():
+    err, subnormal_ok = engine.selftest_mfma(0)
+    assert err == 0.0          # integer data: the assumed A/B/D lane maps are exact or wrong
+    print("fp16 subnormal operands preserved by MFMA:", subnormal_ok)
+
+
+def test_device_is_gfx950():
+    assert "gfx950" in lib.device_name(0)
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["mfma", "exact"])
+def test_goldens_from_unmodified_reference(gold, engines, exact):
+    n = 0
+    for key in sorted(gold["gru_outputs"]):
+        wname, cname = key.split("/")
+        x = gold["gru_inputs"][cname]
+        if exact and x.shape[1] > 2000:
+            continue
+        out = engines(wname, exact).forward_host(x)
+        _check(out, gold["gru_outputs"][key], what=f"{key} exact={exact}")
+        n += 1
+    assert n >= 20
+
+
+def test_consensus_string_identical(gold, engines):
+    """argmax -> '*ACGT' with gaps dropped (reference labels.py:1053-1085) on the engine's
+    probabilities equals the reference's own decode of its own probabilities."""
+    alphabet = np.array(list("*ACGT"))
+    for key in ("trained/synth60", "trained/edge_B3", "trained/testcounts"):
+        cname = key.split("/")[1]
+        out = engines("trained").forward_host(gold["gru_inputs"][cname])
+        for w in range(out.shape[0]):
+            s = "".join(alphabet[out[w].argmax(-1)]).replace("*", "")
+            assert s == str(gold["consensus_decode"][key][w]), key
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (1, 3), (2, 5), (7, 33), (8, 64), (9, 100),
+                                 (17, 257), (3, 1001), (25, 40)])
+def test_ragged_shapes_vs_oracle(gold, engines, B, T):
+    x = synth.counts_windows(B, T, depth=50, seed=1000 + 17 * B + T)
+    for wname in ("x3", "trained"):
+        ref = oracle.c_gru_forward(x, weight_set(gold, wname))
+        _check(engines(wname).forward_host(x), ref, what=f"{wname} B={B} T={T}")
+
+
+def test_uniform_noise_vs_oracle(gold, engines):
+    x = synth.uniform_windows(6, 777, seed=9)     # medaka/test/test_sample.py:50 style input
+    for wname in ("init", "x3"):
+        ref = oracle.c_gru_forward(x, weight_set(gold, wname))
+        _check(engines(wname).forward_host(x), ref, what=wname)
+
+
+def test_exact_and_mfma_kernels_agree_on_device(gold, engines):
+    x = synth.counts_windows(5, 1500, seed=77)
+    a = engines("x3", False).forward_host(x)
+    b = engines("x3", True).forward_host(x)
+    assert np.abs(a - b).max() <= TOL
+
+
+def test_empty_inputs(gold, engines):
+    e = engines("init")
+    assert e.forward_host(np.zeros((0, 10, 10), np.float32)).shape == (0, 10, 5)
+    assert e.forward_host(np.zeros((3, 0, 10), np.float32)).shape == (3, 0, 5)
+    with pytest.raises(ValueError):
+        e.forward_host(np.zeros((3, 4, 9), np.float32))
+
+
+def test_logits_mode(gold, engines):
+    x = synth.counts_windows(2, 50, seed=4)
+    e = engine.GruEngine(weight_set(gold, "x3"), normalise=False)
+    ref = oracle.c_gru_forward(x, weight_set(gold, "x3"), normalise=False)
+    assert np.abs(e.forward_host(x) - ref).max() <= 5e-5
+    e.close()
+
+
+def test_unidirectional_single_layer():
+    rng = np.random.default_rng(3)
+    shapes = [(384, 10), (384, 128), (384,), (384,), (5, 128), (5,)]
+    keys = engine.state_keys(1, False)
+    state = {k: (rng.standard_normal(s) * 0.3).astype(np.float32) for k, s in zip(keys, shapes)}
+    x = synth.counts_windows(3, 200, seed=8)
+    e = engine.GruEngine(state, n_layers=1, bidirectional=False)
+    ref = oracle.c_gru_forward(x, state, n_layers=1, bidirectional=False)
+    _check(e.forward_host(x), ref, what="1 layer unidirectional")
+    e.close()
+
+
+def test_full_batch_properties(gold, engines):
+    """BASELINE configs[1] shape: 200 windows x 10000 columns (2M columns per call)."""
+    B, T = 200, 10000
+    x = np.concatenate([synth.counts_windows(8, T, depth=50, seed=s) for s in range(25)])
+    assert x.shape == (B, T, 10)
+    e = engines("trained")
+    out = e.forward_host(x)
+    assert np.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
+    assert np.abs(out.sum(-1) - 1).max() <= 2e-6                    # softmax rows
+    # windows are independent: permuting the batch permutes the output, bit for bit
+    perm = np.random.default_rng(0).permutation(B)
+    out_p = e.forward_host(x[perm])
+    assert np.array_equal(out_p, out[perm])
+    # and so does splitting it (ragged last tile: 200 = 96 + 104)
+    assert np.array_equal(e.forward_host(x[:96]), out[:96])
+    # spot-check windows against the CPU oracle (seconds at this size)
+    pick = [0, 77, 199]
+    ref = oracle.c_gru_forward(x[pick], gold["weights_trained"])
+    _check(out[pick], ref, what="full batch spot check")
+
+
+def test_model_api_predict_on_batch(gold):
+    st = gold["weights_trained"]
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    m = m.to("cuda").eval()
+    x = synth.counts_windows(4, 300, seed=21)
+    ref = oracle.make_torch_oracle(st).predict(x).numpy()
+    # host tensor in -> cpu float32 tensor out (reference models.py:303-313)
+    p = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x)))
+    assert p.device.type == "cpu" and p.dtype == torch.float32 and tuple(p.shape) == (4, 300, 5)
+    _check(p.numpy(), ref, what="predict_on_batch(host)")
+    # device tensor through forward()
+    y = m(torch.from_numpy(x).cuda())
+    assert y.device.type == "cuda"
+    _check(y.cpu().numpy(), ref, what="forward(device)")
+    # zip(data, class_probs) iterates windows along dim 0 (prediction.py:47)
+    assert len(list(p)) == 4
+    # half(): fp16 weights like the reference GPU default (prediction.py:164-168)
+    m.half()
+    ph = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+    assert np.abs(ph - ref).max() <= 2e-3
+    assert (ph.argmax(-1) == ref.argmax(-1)).mean() > 0.999
+
+
+def test_integration_convert(gold):
+    st = gold["weights_init"]
+    ref_like = oracle.make_torch_oracle(st)
+    ref_like.__class__.__name__ = "GRUModel"
+    ref_like.gru_size = 128
+    ref_like.to_dict = lambda: {"type": "GRUModel", "kwargs": dict(
+        num_features=10, num_classes=5, gru_size=128, n_layers=2, bidirectional=True,
+        time_steps=None, classify_activation=None)}
+    ref_like.device = lambda: torch.device("cpu")
+    assert integration.convert(ref_like, "cpu") is ref_like        # --cpu keeps the reference
+    conv = integration.convert(ref_like, "cuda")
+    assert isinstance(conv, models.GRUModel) and conv.device().type == "cuda"
+    x = synth.uniform_windows(2, 64, seed=1)
+    out = conv.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+    _check(out, ref_like.predict(x).numpy(), what="converted model")
+
+
+def test_majority_vote_model(gold):
+    m = models.MajorityVoteModel().to("cuda").eval()
+    for cname, ref in gold["majority_outputs"].items():
+        x = gold["gru_inputs"][cname]
+        p = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+        assert np.abs(p - ref).max() <= 2e-7
+    assert np.abs(engine.majority_forward_host(gold["gru_inputs"]["uniform"]) -
+                  oracle.c_majority_forward(gold["gru_inputs"]["uniform"])).max() <= 2e-7
