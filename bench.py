@@ -43,32 +43,45 @@ def parse():
     ap.add_argument("--batch", type=int, default=200, help="windows per step per GPU")
     ap.add_argument("--chunk-len", type=int, default=10000, help="pileup columns per window")
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--cpu-sample", type=int, default=16, help="windows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="windows in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
     return ap.parse_args()
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(state, x_sample, probs_sample):
-    """Reference CPU path on a bounded sample; also the parity check of the same run."""
+    """Reference CPU path on a bounded sample; also the parity check of the same run.
+
+    PyTorch-CPU GRU scales poorly with threads (reference README.md:332-336 advises <= 2), so
+    a short sweep over thread counts is timed and the fastest is reported with its count."""
     import numpy as np
     import torch
     from oracle import oracle
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     m = oracle.make_torch_oracle(state)
-    m.predict(x_sample[:2])                      # warm-up
-    times, ref = [], None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        ref = m.predict(x_sample)
-        times.append(time.perf_counter() - t0)
-    ref = ref.numpy()
     cols = x_sample.shape[0] * x_sample.shape[1]
-    base = {"value": cols / statistics.median(times), "unit": "pileup columns/s", "cores": cores,
-            "kind": "port",
+    best, ref, sweep = None, None, {}
+    for nthreads in sorted({t for t in (2, 8, 32) if t <= cores} | {min(cores, 2)}):
+        torch.set_num_threads(nthreads)
+        m.predict(x_sample[:1, :500])                # warm-up
+        t0 = time.perf_counter()
+        out = m.predict(x_sample)
+        dt = time.perf_counter() - t0
+        sweep[nthreads] = cols / dt
+        log(f"cpu baseline: {nthreads} threads -> {cols / dt:,.0f} columns/s ({dt:.1f}s)")
+        if best is None or cols / dt > best[1]:
+            best = (nthreads, cols / dt)
+        ref = out.numpy() if ref is None else ref
+        if dt > 25:
+            break
+    base = {"value": best[1], "unit": "pileup columns/s", "cores": best[0], "kind": "port",
+            "host_cores_available": cores, "thread_sweep_columns_per_s": sweep,
             "sample": f"{x_sample.shape[0]} windows x {x_sample.shape[1]} columns, PyTorch-CPU fp32 "
-                      f"nn.GRU+Linear+softmax (the ops of reference gru.py:66-71), "
-                      f"torch threads={torch.get_num_threads()}, median of 3"}
+                      f"nn.GRU+Linear+softmax (the ops of reference gru.py:66-71), one timed pass "
+                      f"per thread count, best reported"}
     parity = {"max_abs_dp": float(np.abs(probs_sample - ref).max()),
               "argmax_identical": bool((probs_sample.argmax(-1) == ref.argmax(-1)).all()),
               "tolerance": 1e-4, "columns_checked": int(cols)}
@@ -83,6 +96,7 @@ def main():
     graft.build()
     from medaka_amd import dist, models, synth
 
+    log('start')
     ranks = dist.Ranks()
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: launch with "
@@ -106,6 +120,7 @@ def main():
     x_host = synth.counts_windows(base_tiles, T, depth=args.depth, seed=1234 + ranks.rank)
     reps = -(-B // base_tiles)
     x_host = np.concatenate([x_host] * reps)[:B]
+    log('synthetic input ready')
     x_dev = torch.from_numpy(x_host).to(dev)
     eng = model.engine()
     eng.enable_timing(True)
@@ -126,8 +141,10 @@ def main():
         head_ms.append(t["head_ms"])
         total_ms.append(t["total_ms"])
 
+    log('engine ready, timing')
     elapsed, mine = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev),
                                      steps=args.steps, warmup=args.warmup)
+    log(f'timed region done: {elapsed:.3f}s for {args.steps} steps')
     # keep only the timed steps' kernel records
     n_layers = len(eng.timing()["rec_ms"])
     rec_ms = rec_ms[-args.steps * n_layers:]

@@ -93,8 +93,8 @@ int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_
 /*
  * Same contraction with device-resident buffers (what `GRUModel.forward`, gru.py:58-72, is to
  * `predict_on_batch`).  x_dev / probs_dev are device pointers valid on the model's device;
- * `stream` is a hipStream_t (NULL = the model's own stream).  Asynchronous with respect to the
- * host unless timing is enabled.
+ * `stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it, in order.
+ * Asynchronous with respect to the host unless timing is enabled.
  */
 int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
                         void *stream);

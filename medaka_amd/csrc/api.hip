@@ -412,7 +412,7 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     if (B == 0 || T == 0) return MDK_OK;
     if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t s = (hipStream_t)stream;   // NULL = the legacy default stream, as for any HIP call
     // windows per pass, bounded so that the workspace stays within a fixed column budget
     size_t per_pass = std::max<size_t>(1, kMaxRowsPerPass / (size_t)T);
     per_pass = std::min<size_t>(per_pass, (size_t)B);

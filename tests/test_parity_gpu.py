@@ -123,7 +123,7 @@ def test_unidirectional_single_layer():
     rng = np.random.default_rng(3)
     shapes = [(384, 10), (384, 128), (384,), (384,), (5, 128), (5,)]
     keys = engine.state_keys(1, False)
-    state = {k: (rng.standard_normal(s) * 0.3).astype(np.float32) for k, s in zip(keys, shapes)}
+    state = {k: (rng.standard_normal(s) * 0.08).astype(np.float32) for k, s in zip(keys, shapes)}
     x = synth.counts_windows(3, 200, seed=8)
     e = engine.GruEngine(state, n_layers=1, bidirectional=False)
     ref = oracle.c_gru_forward(x, state, n_layers=1, bidirectional=False)
