@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--chunk-len", type=int, default=10000, help="pileup columns per window")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=8, help="windows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
+    ap.add_argument("--tile", type=int, default=0, help="recurrence windows per tile (0 auto, 4, 8)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
     return ap.parse_args()
 
@@ -113,6 +115,7 @@ def main():
     model = model.to(dev).eval()
     if args.half:
         model.half()
+    model.kernel_variant = args.variant
 
     # synthetic 50x pileup windows, one distinct shard per rank (seeded by rank); generated in
     # tiles of 8 windows and repeated to B to keep host set-up time small
@@ -123,6 +126,7 @@ def main():
     log('synthetic input ready')
     x_dev = torch.from_numpy(x_host).to(dev)
     eng = model.engine()
+    eng.set_option("rec_windows_per_tile", args.tile)
     eng.enable_timing(True)
 
     out_holder = {}

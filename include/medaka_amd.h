@@ -105,6 +105,10 @@ int mdk_gru_set_variant(mdk_gru *m, int variant);
 /* `normalise` attribute of GRUModel (gru.py:56,68): 1 softmax, 0 logits. */
 int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 
+/* Tuning knobs (no reference counterpart): "rec_windows_per_tile" = 0 (auto) | 4 | 8;
+ * "ablate" = timing-only ablation mask of the recurrence kernel (results invalid unless 0). */
+int mdk_gru_set_option(mdk_gru *m, const char *key, int value);
+
 /* hipEvent timing of every kernel of the following forwards (adds a stream sync per forward). */
 int mdk_gru_enable_timing(mdk_gru *m, int on);
 int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);

@@ -16,10 +16,15 @@
 #include "common.hpp"
 #include "exact.hpp"
 #include "gi_proj.hpp"
+#include "layout.hpp"
 #include "head.hpp"
 #include "rec_mfma.hpp"
 
 using namespace mdk;
+
+#ifndef MDK_PF
+#define MDK_PF 4
+#endif
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -57,7 +62,9 @@ struct LayerDev {
     float *w_hh_t = nullptr;      // [D][128][384] fp32
     float *bias_gi = nullptr;     // [D][384]
     float *b_hn = nullptr;        // [D][128]
-    half8 *whh_frag = nullptr;    // [D][4][6][4][2][64]
+    half8 *whh_frag = nullptr;    // [D][8 waves][4 ks][3 gates][2 hi/lo][64 lanes]
+    float *ones = nullptr;        // [D] = 1
+    float *up_scale_rec = nullptr;   // [D] = 1/inv_scale_rec
     half8 *wih_frag = nullptr;    // [D][2][4][K/32][3][2][64] (layers >= 1)
     float *inv_scale_rec = nullptr;  // [D]
     float *inv_scale_gi = nullptr;   // [D]
@@ -69,6 +76,8 @@ struct mdk_gru {
     int D = 2;
     int precision = MDK_PREC_FP32;
     int variant = MDK_VARIANT_MFMA;
+    int opt_tile_windows = 0;   // 0 auto, 4, 8
+    int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
     std::vector<LayerDev> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace (grown on demand)
@@ -92,7 +101,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     (void)hipSetDevice(m->device);
     for (auto &L : m->layers) {
         free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
-        free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
+        free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->x_dev); free_dev(m->p_dev);
@@ -160,7 +169,8 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         std::vector<float> w_ih_t((size_t)D * K * kG), w_hh_t((size_t)D * kH * kG);
         std::vector<float> bias_gi((size_t)D * kG), b_hn((size_t)D * kH);
         std::vector<float> inv_rec(D), inv_gi(D);
-        std::vector<half8> whh_frag((size_t)D * 4 * 6 * 4 * 2 * 64);
+        std::vector<half8> whh_frag((size_t)D * 8 * 4 * 3 * 2 * 64);
+        std::vector<float> ones(D, 1.0f), up_rec(D);
         const int KS = (K % 32 == 0) ? K / 32 : 0;
         std::vector<half8> wih_frag;
         if (l > 0) wih_frag.resize((size_t)D * 4 * KS * 6 * 2 * 64);
@@ -175,28 +185,26 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
                 bias_gi[(size_t)d * kG + j] = b_ih[j] + (j < 2 * kH ? b_hh[j] : 0.0f);
             }
             for (int j = 0; j < kH; ++j) b_hn[(size_t)d * kH + j] = b_hh[2 * kH + j];
-            // recurrent B-fragments (rec_mfma.hpp): tile t6 = s*3 + gate, column n = lane&15
+            // recurrent B-fragments (rec_mfma.hpp): wave w8 owns units 16*w8..+15, column n = lane&15
             const float sw = pick_scale(w_hh, (size_t)kG * kH);
             inv_rec[d] = 1.0f / (kActScale * sw);
-            for (int w = 0; w < 4; ++w)
-                for (int s = 0; s < 2; ++s)
+            up_rec[d] = kActScale * sw;
+            for (int w8 = 0; w8 < 8; ++w8)
+                for (int ks = 0; ks < 4; ++ks)
                     for (int gate = 0; gate < 3; ++gate)
-                        for (int ks = 0; ks < 4; ++ks)
-                            for (int lane = 0; lane < 64; ++lane) {
-                                const int n = lane & 15, gq = lane >> 4;
-                                const int j = gate * kH + 32 * w + 16 * s + n;
-                                half8 hi, lo;
-                                for (int i = 0; i < 8; ++i) {
-                                    const int k = rec_unit_of_slot(ks, gq, i);
-                                    _Float16 a, b;
-                                    split_host(w_hh[(size_t)j * kH + k] * sw, a, b);
-                                    hi[i] = a; lo[i] = b;
-                                }
-                                const int t6 = s * 3 + gate;
-                                const size_t base = ((((size_t)(d * 4 + w) * 6 + t6) * 4 + ks) * 2) * 64 + lane;
-                                whh_frag[base] = hi;
-                                whh_frag[base + 64] = lo;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int j = gate * kH + 16 * w8 + (lane & 15);
+                            const int gq = lane >> 4;
+                            half8 hi, lo;
+                            for (int i = 0; i < 8; ++i) {
+                                _Float16 a, b;
+                                split_host(w_hh[(size_t)j * kH + 32 * ks + 8 * gq + i] * sw, a, b);
+                                hi[i] = a; lo[i] = b;
                             }
+                            const size_t base = ((((size_t)(d * 8 + w8) * 4 + ks) * 3 + gate) * 2) * 64 + lane;
+                            whh_frag[base] = hi;
+                            whh_frag[base + 64] = lo;
+                        }
             if (l > 0) {
                 const float swi = pick_scale(w_ih, (size_t)kG * K);
                 inv_gi[d] = 1.0f / (kActScale * swi);
@@ -205,7 +213,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
                         for (int ks = 0; ks < KS; ++ks)
                             for (int nt = 0; nt < 3; ++nt)
                                 for (int lane = 0; lane < 64; ++lane) {
-                                    const int col = gemm_col(nhalf, w, nt, lane & 15);
+                                    const int col = nt * kH + 16 * (4 * nhalf + w) + (lane & 15);   // gate nt, unit
                                     const int gq = lane >> 4;
                                     half8 hi, lo;
                                     for (int i = 0; i < 8; ++i) {
@@ -227,6 +235,8 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         if ((rc = upload(&Ld.bias_gi, bias_gi))) return bail(rc);
         if ((rc = upload(&Ld.b_hn, b_hn))) return bail(rc);
         if ((rc = upload(&Ld.whh_frag, whh_frag))) return bail(rc);
+        if ((rc = upload(&Ld.ones, ones))) return bail(rc);
+        if ((rc = upload(&Ld.up_scale_rec, up_rec))) return bail(rc);
         if (l > 0 && (rc = upload(&Ld.wih_frag, wih_frag))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_rec, inv_rec))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_gi, inv_gi))) return bail(rc);
@@ -260,6 +270,18 @@ extern "C" int mdk_gru_set_variant(mdk_gru *m, int variant) {
 extern "C" int mdk_gru_set_normalise(mdk_gru *m, int normalise) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     m->desc.normalise = normalise ? 1 : 0;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
+    if (!m || !key) return fail(MDK_ERR_ARG, "null argument");
+    if (!strcmp(key, "rec_windows_per_tile")) {
+        if (value != 0 && value != 4 && value != 8) return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4 or 8");
+        m->opt_tile_windows = value;
+    } else if (!strcmp(key, "ablate")) {
+        m->opt_ablate = value;
+    } else {
+        return fail(MDK_ERR_ARG, "unknown option '%s'", key);
+    }
     return MDK_OK;
 }
 extern "C" int mdk_gru_enable_timing(mdk_gru *m, int on) {
@@ -321,46 +343,99 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                         EvTimer &tm) {
     const int D = m->D, L = m->desc.num_layers;
     const long M = (long)nb * T;
-    const size_t gi_dir_stride = (size_t)M * kG;
-    const int out_stride = D * kH;
     const int reverse_mask = (D == 2) ? 2 : 0;
     const bool exact = (m->variant == MDK_VARIANT_EXACT);
+    const int n_tiles = (nb + kTileWin - 1) / kTileWin;
     int rc;
     const float *in = x;
+    if (exact) {
+        // natural [window][t][f] layouts, plain fp32 kernels
+        const size_t gi_dir_stride = (size_t)M * kG;
+        const int out_stride = D * kH;
+        for (int l = 0; l < L; ++l) {
+            const LayerDev &Ld = m->layers[l];
+            float *outp = m->act[l & 1];
+            if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
+            hipLaunchKernelGGL(k_gi_exact, dim3((unsigned)(3 * M), D), dim3(128), 0, s, in, Ld.w_ih_t,
+                               Ld.bias_gi, m->gi, M, Ld.K, gi_dir_stride, Ld.ones);
+            if ((rc = tm.end())) return rc;
+            if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
+            hipLaunchKernelGGL(k_rec_exact, dim3(nb, D), dim3(128), 0, s, m->gi, Ld.w_hh_t, Ld.b_hn, outp,
+                               nb, T, out_stride, gi_dir_stride, reverse_mask);
+            if ((rc = tm.end())) return rc;
+            m->last.rec_launches++;
+            in = outp;
+        }
+        if ((rc = tm.begin(SLOT_HEAD))) return rc;
+        long blocks = std::min<long>((M + 15) / 16, 256 * 16);
+        if (D == 2)
+            hipLaunchKernelGGL(k_linear_softmax<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
+                               m->lin_b, probs, M, m->desc.normalise);
+        else
+            hipLaunchKernelGGL(k_linear_softmax<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
+                               m->lin_b, probs, M, m->desc.normalise);
+        if ((rc = tm.end())) return rc;
+        HIP_TRY(hipGetLastError());
+        return MDK_OK;
+    }
+
+    // ---- production path: tile-major intermediates (layout.hpp)
+    if (m->layers[0].K > 16)
+        return fail(MDK_ERR_ARG, "num_features %d > 16 is only supported by MDK_VARIANT_EXACT", m->layers[0].K);
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
-        // ---- input projection
         if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
-        if (exact || (l == 0 && Ld.K > 16) || (l > 0 && Ld.K != 256 && Ld.K != 128)) {
-            hipLaunchKernelGGL(k_gi_exact, dim3((unsigned)(3 * M), D), dim3(128), 0, s, in, Ld.w_ih_t,
-                               Ld.bias_gi, m->gi, M, Ld.K, gi_dir_stride);
-        } else if (l == 0) {
-            const int rpb = 64;
-            hipLaunchKernelGGL(k_gi_small<16>, dim3((unsigned)((M + rpb - 1) / rpb), D), dim3(192), 0, s,
-                               in, Ld.w_ih_t, Ld.bias_gi, m->gi, M, Ld.K, gi_dir_stride, rpb);
+        if (l == 0) {
+            const int tpb = 128;
+            hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, in,
+                               Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec);
         } else {
-            const unsigned grid = (unsigned)((M + kGemmRows - 1) / kGemmRows);
-            if (Ld.K == 256) {
-                const size_t lds = (size_t)2 * 8 * 8 * 64 * sizeof(half8);
-                hipLaunchKernelGGL(k_gi_gemm<8>, dim3(grid), dim3(256), lds, s, in, Ld.wih_frag,
-                                   Ld.bias_gi, m->gi, M, D, gi_dir_stride, Ld.inv_scale_gi);
-            } else {
-                const size_t lds = (size_t)2 * 8 * 4 * 64 * sizeof(half8);
-                hipLaunchKernelGGL(k_gi_gemm<4>, dim3(grid), dim3(256), lds, s, in, Ld.wih_frag,
-                                   Ld.bias_gi, m->gi, M, D, gi_dir_stride, Ld.inv_scale_gi);
-            }
+            const dim3 grid((T + kGemmSteps - 1) / kGemmSteps, n_tiles);
+            if (D == 2)
+                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(256), (size_t)2 * 8 * 8 * 64 * sizeof(half8), s, in,
+                                   Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
+                                   Ld.up_scale_rec);
+            else
+                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(256), (size_t)2 * 8 * 4 * 64 * sizeof(half8), s, in,
+                                   Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
+                                   Ld.up_scale_rec);
         }
         if ((rc = tm.end())) return rc;
-        // ---- recurrence
         if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
-        if (exact) {
-            hipLaunchKernelGGL(k_rec_exact, dim3(nb, D), dim3(128), 0, s, m->gi, Ld.w_hh_t, Ld.b_hn, outp,
-                               nb, T, out_stride, gi_dir_stride, reverse_mask);
-        } else {
-            hipLaunchKernelGGL(k_rec_mfma<4>, dim3((nb + kRecSeqs - 1) / kRecSeqs, D), dim3(256), 0, s,
-                               m->gi, Ld.whh_frag, Ld.b_hn, outp, nb, T, out_stride, gi_dir_stride,
-                               Ld.inv_scale_rec, reverse_mask);
+        {
+            // "ablate" option / MDK_ABLATE=<mask>: timing-only ablations (wrong results)
+            static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
+            const int abl = m->opt_ablate ? m->opt_ablate : env_abl;
+            // half-tile (4-window) work-groups while they fit the chip in one round, else whole tiles
+            int nq = (2 * n_tiles) * D <= 256 ? 1 : 2;
+            if (m->opt_tile_windows == 4) nq = 1;
+            if (m->opt_tile_windows == 8) nq = 2;
+            const dim3 grid(nq == 1 ? 2 * n_tiles : n_tiles, D);
+#define MDK_LAUNCH_REC(A)                                                                          \
+    do {                                                                                           \
+        if (nq == 1)                                                                               \
+            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 1, A>), grid, dim3(512), 0, s, m->gi, Ld.whh_frag, \
+                               Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, reverse_mask);      \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 2, A>), grid, dim3(512), 0, s, m->gi, Ld.whh_frag, \
+                               Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, reverse_mask);      \
+    } while (0)
+            switch (abl) {
+                case 0: MDK_LAUNCH_REC(0); break;
+                case 1: MDK_LAUNCH_REC(1); break;
+                case 2: MDK_LAUNCH_REC(2); break;
+                case 3: MDK_LAUNCH_REC(3); break;
+                case 4: MDK_LAUNCH_REC(4); break;
+                case 7: MDK_LAUNCH_REC(7); break;
+                case 8: MDK_LAUNCH_REC(8); break;
+                case 15: MDK_LAUNCH_REC(15); break;
+                case 16: MDK_LAUNCH_REC(16); break;
+                case 24: MDK_LAUNCH_REC(24); break;
+                case 31: MDK_LAUNCH_REC(31); break;
+                default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
+            }
+#undef MDK_LAUNCH_REC
         }
         if ((rc = tm.end())) return rc;
         m->last.rec_launches++;
@@ -368,15 +443,14 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     }
     if ((rc = tm.begin(SLOT_HEAD))) return rc;
     {
-        const long rows_per_block = 16;  // 4 waves x 4 rows
-        long blocks = (M + rows_per_block - 1) / rows_per_block;
-        if (blocks > 256 * 16) blocks = 256 * 16;
+        const long n_blocks = (long)n_tiles * T;
+        const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
         if (D == 2)
-            hipLaunchKernelGGL(k_linear_softmax<4>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
-                               m->lin_b, probs, M, m->desc.normalise);
+            hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
+                               probs, nb, T, n_tiles, m->desc.normalise);
         else
-            hipLaunchKernelGGL(k_linear_softmax<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w,
-                               m->lin_b, probs, M, m->desc.normalise);
+            hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
+                               probs, nb, T, n_tiles, m->desc.normalise);
     }
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
@@ -416,8 +490,8 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     // windows per pass, bounded so that the workspace stays within a fixed column budget
     size_t per_pass = std::max<size_t>(1, kMaxRowsPerPass / (size_t)T);
     per_pass = std::min<size_t>(per_pass, (size_t)B);
-    if (per_pass >= kRecSeqs) per_pass -= per_pass % kRecSeqs;   // full recurrence tiles
-    int rc = ensure_workspace(m, per_pass * (size_t)T);
+    if (per_pass >= 8) per_pass -= per_pass % 8;   // full recurrence tiles
+    int rc = ensure_workspace(m, ((per_pass + kTileWin - 1) / kTileWin * kTileWin) * (size_t)T);
     if (rc) return rc;
     EvTimer tm{m, s};
     for (size_t b0 = 0; b0 < (size_t)B; b0 += per_pass) {

@@ -10,7 +10,7 @@ namespace mdk {
 // gi[d][m][n] = sum_k x[m][k] * w_ih_t[d][k][n] + bias[d][n];  one thread per (m, n)
 __global__ __launch_bounds__(128) void k_gi_exact(
     const float *__restrict__ x, const float *__restrict__ w_ih_t, const float *__restrict__ bias,
-    float *__restrict__ gi, long M, int K, size_t gi_dir_stride)
+    float *__restrict__ gi, long M, int K, size_t gi_dir_stride, const float *__restrict__ out_scale_p)
 {
     const int d = blockIdx.y;
     const long m = blockIdx.x / 3;
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(128) void k_gi_exact(
     const float *wt = w_ih_t + (size_t)d * K * kG + n;
     float acc = 0.f;
     for (int k = 0; k < K; ++k) acc = fmaf(xr[k], wt[(size_t)k * kG], acc);
-    gi[(size_t)d * gi_dir_stride + (size_t)m * kG + n] = acc + bias[(size_t)d * kG + n];
+    gi[(size_t)d * gi_dir_stride + (size_t)m * kG + n] = (acc + bias[(size_t)d * kG + n]) * out_scale_p[d];
 }
 
 // one 128-thread work-group per (window, direction); thread j owns hidden unit j

@@ -6,99 +6,112 @@
 //  * k_gi_gemm  : layers >= 1, K = 256 (or 128).  49 % of the network's FLOPs.  fp16x2-split
 //                 MFMA GEMM (three products hi*hi + lo*hi + hi*lo into one fp32 accumulator,
 //                 operands pre-scaled by powers of two), fp32 in / fp32 out.
+// Both write gi in the tile-major register order of the recurrence kernel (layout.hpp); the
+// GEMM also reads the previous layer's activations in that order, so both are streaming kernels
+// over contiguous blocks.
 // The folded bias is b_ih + b_hh for the r and z gates and b_ih for n (b_hn must stay inside
 // the r * (.) product, see rec_mfma.hpp).
 #pragma once
 #include "common.hpp"
+#include "layout.hpp"
 
 namespace mdk {
 
 // ------------------------------------------------------------------------------------------
-// layer 0: each thread owns 4 consecutive gate columns for a strip of rows; its 4 x K weights
-// stay in registers.
+// layer 0.  One 768-thread work-group per (tile, direction, strip of time steps); thread f4 owns
+// float4 number f4 of every 12 KB gi block of its tile = 4 consecutive hidden units of one
+// (w8, q, gate) for window-group g; its 4 x K weights stay in registers; x rows are tiny
+// broadcast loads.  Every block is written as one contiguous 12 KB run.
 template <int KMAX>
-__global__ __launch_bounds__(192) void k_gi_small(
-    const float *__restrict__ x,      // [M][K]
+__global__ __launch_bounds__(768) void k_gi_small(
+    const float *__restrict__ x,      // [B][T][K] natural layout (the reference's batch tensor)
     const float *__restrict__ w_ih_t, // [D][K][384]  (transposed at load time)
     const float *__restrict__ bias,   // [D][384]     folded bias
-    float *__restrict__ gi,           // [D][M][384]
-    long M, int K, size_t gi_dir_stride, int rows_per_block)
+    float *__restrict__ gi,           // gi_t
+    int B, int T, int K, int n_tiles, int t_per_block, const float *__restrict__ out_scale_p)
 {
+    const int tile = blockIdx.x;
     const int d = blockIdx.y;
-    const int c4 = threadIdx.x % 96;   // float4 column
-    const int rsel = threadIdx.x / 96; // 0/1: even / odd rows of the strip
+    const float os = out_scale_p[d];
+    const int f4 = threadIdx.x;
+    const int c4 = f4 & 3, g = (f4 >> 2) & 3, rest = f4 >> 4;   // rest = (w8*2+q)*3 + gate
+    const int gate = rest % 3, wq = rest / 3, q = wq & 1, w8 = wq >> 1;
+    const int j0 = gate * kH + 16 * w8 + 4 * c4;
     float4 wreg[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        wreg[k] = (k < K)
-            ? *reinterpret_cast<const float4 *>(w_ih_t + ((size_t)d * K + k) * kG + 4 * c4)
-            : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float4 b = *reinterpret_cast<const float4 *>(bias + (size_t)d * kG + 4 * c4);
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
-    float *gout = gi + (size_t)d * gi_dir_stride;
-    for (long r = r0 + rsel; r < r1; r += 2) {
-        const float *xr = x + r * K;
+    for (int k = 0; k < KMAX; ++k)
+        wreg[k] = (k < K) ? *reinterpret_cast<const float4 *>(w_ih_t + ((size_t)d * K + k) * kG + j0)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = *reinterpret_cast<const float4 *>(bias + (size_t)d * kG + j0);
+    const int win = tile * kTileWin + 2 * g + q;
+    const bool real = win < B;          // padding windows of the last tile see x = 0
+    const float *xw = x + (size_t)(real ? win : 0) * T * K;
+    const int t0 = blockIdx.z * t_per_block;
+    const int t1 = min(T, t0 + t_per_block);
+    float *gout = gi + gi_block(d, n_tiles, tile, T, t0) + 4 * f4;
+    for (int t = t0; t < t1; ++t, gout += kGiBlock) {
+        const float *xr = xw + (size_t)t * K;
         float4 acc = b;
+        if (real) {
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                const float xv = xr[k];
-                acc.x = fmaf(xv, wreg[k].x, acc.x);
-                acc.y = fmaf(xv, wreg[k].y, acc.y);
-                acc.z = fmaf(xv, wreg[k].z, acc.z);
-                acc.w = fmaf(xv, wreg[k].w, acc.w);
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float xv = xr[k];
+                    acc.x = fmaf(xv, wreg[k].x, acc.x);
+                    acc.y = fmaf(xv, wreg[k].y, acc.y);
+                    acc.z = fmaf(xv, wreg[k].z, acc.z);
+                    acc.w = fmaf(xv, wreg[k].w, acc.w);
+                }
             }
         }
-        *reinterpret_cast<float4 *>(gout + (size_t)r * kG + 4 * c4) = acc;
+        acc.x *= os; acc.y *= os; acc.z *= os; acc.w *= os;   // exact: os is a power of two
+        *reinterpret_cast<float4 *>(gout) = acc;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// layers >= 1.  Work-group = 4 waves, tile = 128 rows x 384 columns (one direction at a time,
-// both directions from the same LDS-resident x tile).  The x tile is converted once to fp16
-// hi/lo A-fragments in LDS (128 KB at K = 256); W_ih B-fragments stream from L2 (pre-packed so
-// that every lane issues one 16-byte load per fragment).  Per (direction, column-half) pass wave
-// w owns 48 columns (gemm_col()).
-constexpr int kGemmRows = 128;
-// gate column owned by (column half, wave, column tile, lane&15)
-__host__ __device__ inline int gemm_col(int nhalf, int w, int nt, int n) {
-    return nhalf * 192 + 48 * w + 16 * nt + n;
-}
+// layers >= 1.  Work-group = 4 waves, M-tile = one window tile x 16 time steps = 128 rows, read
+// as ONE contiguous run of 16 activation blocks.  MFMA row 4g + 2q + tt of row-tile mt is
+// (window 2g+q, t0 + 2*mt + tt), so accumulator register r = 2q + tt of lane g*16+c is exactly
+// element `lane` of gi block t0+2mt+tt, sub-block (w8, q, gate): every accumulator register is
+// stored by the wave as one contiguous 256-byte run.  The x tile is converted once to fp16
+// hi/lo A-fragments in LDS (128 KB at K = 256); W_ih B-fragments stream from L2, pre-packed so
+// that each lane issues one 16-byte load per fragment.  2*D passes (direction, unit half ph):
+// wave w owns units 16*(4*ph + w) .. +15 of all three gates.
+constexpr int kGemmSteps = 16;
 
-template <int KSTEPS>   // K = 32 * KSTEPS
+template <int KSTEPS>   // K = 32 * KSTEPS = D_in * 128
 __global__ __launch_bounds__(256, 1) void k_gi_gemm(
-    const float *__restrict__ x,       // [M][K] fp32 (|x| < 1: GRU outputs)
-    const half8 *__restrict__ wfrag,   // [D][2 halves][4 waves][KSTEPS][3 tiles][2 hi/lo][64 lanes]
+    const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
+    const half8 *__restrict__ wfrag,   // [D][2 ph][4 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
     const float *__restrict__ bias,    // [D][384]
-    float *__restrict__ gi,            // [D][M][384]
-    long M, int D, size_t gi_dir_stride, const float *__restrict__ inv_scale_p)
+    float *__restrict__ gi,            // gi_t
+    int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
+    const float *__restrict__ out_scale_p)
 {
-    constexpr int K = 32 * KSTEPS;
+    constexpr int DIN = KSTEPS / 4;            // directions of the input activations
+    constexpr int NP = DIN * 128;              // 8-float pieces per activation block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *xs = reinterpret_cast<half8 *>(smem);   // [split 2][mt 8][KSTEPS][64 lanes]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long m0 = (long)blockIdx.x * kGemmRows;
+    const int tile = blockIdx.y;
+    const int t0 = blockIdx.x * kGemmSteps;
 
-    // ---- stage x tile: wave-item = 8 rows x 8 k-octets; lane = (k-octet hi3, row lo3)
+    // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)
     {
-        const int r_lo = lane & 7, k_lo = lane >> 3;
-        constexpr int KB = K / 64;               // k-octet blocks per row
-        constexpr int ITEMS = 16 * KB;           // 16 row blocks
-        for (int it = w; it < ITEMS; it += 4) {
-            const int rb = it / KB, kb = it % KB;
-            const int r = rb * 8 + r_lo;         // 0..127
-            const int k8 = kb * 8 + k_lo;        // k-octet 0..K/8-1
-            const long m = m0 + r;
+        const float *src0 = act_in + act_block(DIN, tile, T, t0);
+        for (int P = tid; P < kGemmSteps * NP; P += 256) {
+            const int tau = P / NP, j = P % NP;
+            const int g = j & 3, q = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
+            const int piece = chunk * 16 + q * 8 + g * 2 + half;
             float v[8];
-            if (m < M) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(x + m * K + k8 * 8);
-                const float4 v1 = *reinterpret_cast<const float4 *>(x + m * K + k8 * 8 + 4);
+            if (t0 + tau < T) {
+                const float *src = src0 + (size_t)tau * (DIN * 1024) + piece * 8;
+                const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
                 v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
                 v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
             } else {
@@ -112,17 +125,19 @@ __global__ __launch_bounds__(256, 1) void k_gi_gemm(
                 split_f16(v[i] * kActScale, a, b);
                 hi[i] = a; lo[i] = b;
             }
-            const int mt = r >> 4, ks = k8 >> 2;
-            const int slot = (k8 & 3) * 16 + (r & 15);   // A-fragment lane that consumes it
+            const int row = 4 * g + 2 * q + (tau & 1), mt = tau >> 1;
+            const int k8 = chunk * 2 + half, ks = k8 >> 2;
+            const int slot = (k8 & 3) * 16 + row;      // A-fragment lane that consumes it
             xs[((0 * 8 + mt) * KSTEPS + ks) * 64 + slot] = hi;
             xs[((1 * 8 + mt) * KSTEPS + ks) * 64 + slot] = lo;
         }
     }
     __syncthreads();
 
-    // 2*D passes: (direction, column half); wave w owns 48 columns = 3 MFMA column tiles per pass
+    const int g = lane >> 4;
     for (int pass = 0; pass < 2 * D; ++pass) {
-        const int d = pass >> 1, nhalf = pass & 1;
+        const int d = pass >> 1, ph = pass & 1;
+        const int w8 = 4 * ph + w;
         floatx4 acc[8][3];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -151,25 +166,28 @@ __global__ __launch_bounds__(256, 1) void k_gi_gemm(
             }
         }
 
-        // ---- epilogue: scale back, add folded bias, store fp32
-        const float inv_scale = inv_scale_p[d];
-        float *gout = gi + (size_t)d * gi_dir_stride;
-        const int col0 = gemm_col(nhalf, w, 0, lane & 15);
-        const int rg = (lane >> 4) * 4;
+        // ---- epilogue: scale back, add folded bias, 256-byte runs per accumulator register
+        const float os = out_scale_p[d];
+        const float inv_scale = inv_scale_p[d] * os;   // powers of two: exact
+        float bv[3];
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            const int col = col0 + 16 * nt;
-            const float b = bias[(size_t)d * kG + col];
+        for (int nt = 0; nt < 3; ++nt) bv[nt] = bias[(size_t)d * kG + nt * kH + 16 * w8 + (lane & 15)] * os;
+        float *gblk = gi + gi_block(d, n_tiles, tile, T, t0);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long m = m0 + mt * 16 + rg + r;
-                    if (m < M) gout[(size_t)m * kG + col] = fmaf(acc[mt][nt][r], inv_scale, b);
+            for (int r = 0; r < 4; ++r) {
+                const int q = r >> 1, tt = r & 1;
+                const int t = t0 + 2 * mt + tt;
+                if (t < T) {
+                    float *dst = gblk + (size_t)(2 * mt + tt) * kGiBlock + gi_in_block(w8, q, 0, lane);
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
                 }
             }
         }
     }
+    (void)g;
 }
 
 }  // namespace mdk

@@ -4,6 +4,7 @@
 // Both are HBM-streaming kernels: one 1 KB row in, 20 B out.
 #pragma once
 #include "common.hpp"
+#include "layout.hpp"
 
 namespace mdk {
 
@@ -76,6 +77,78 @@ __global__ __launch_bounds__(256) void k_linear_softmax(
             v = sub == 3 ? res[3] : v;
             v = sub == 4 ? res[4] : v;
             probs[row * 5 + sub] = v;
+        }
+    }
+}
+
+// Same head over the tile-major activation layout (layout.hpp) written by the recurrence kernel.
+// One wave per (tile, t) block = the rows of 8 windows.  Lane l reads float4 number i*64 + l of
+// the block for i = 0..DIN*4-1: it always sees window (g, q) = ((l>>2)&3, (l>>4)&1) and features
+// 16*(2i + (l>>5)) + 4*(l&3) .. +3; the 8 lanes of a window are xor-reduced (masks 1, 2, 32).
+// Probabilities go out in the reference's natural (B, T, 5) order.
+template <int DIN>
+__global__ __launch_bounds__(256) void k_head_tiled(
+    const float *__restrict__ act,    // act_t of the last layer
+    const float *__restrict__ lin_w,  // [5][DIN*128]
+    const float *__restrict__ lin_b,  // [5]
+    float *__restrict__ probs,        // [B][T][5]
+    int B, int T, int n_tiles, int normalise)
+{
+    constexpr int F = DIN * 128;
+    __shared__ __attribute__((aligned(16))) float wl[5 * F];
+    for (int i = threadIdx.x; i < 5 * F; i += blockDim.x) wl[i] = lin_w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int c4 = lane & 3, g = (lane >> 2) & 3, q = (lane >> 4) & 1, hi = lane >> 5;
+    float bv[5];
+#pragma unroll
+    for (int cl = 0; cl < 5; ++cl) bv[cl] = lin_b[cl];
+    const long n_blocks = (long)n_tiles * T;
+    const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long n_waves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long blk = wave_global; blk < n_blocks; blk += n_waves) {
+        const int tile = (int)(blk / T), t = (int)(blk % T);
+        const float *src = act + (size_t)blk * (DIN * 1024) + 4 * lane;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < DIN * 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + i * 256);
+            const int f0 = 16 * (2 * i + hi) + 4 * c4;
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) {
+                const float4 wv = *reinterpret_cast<const float4 *>(&wl[cl * F + f0]);
+                acc[cl] = fmaf(v.x, wv.x, acc[cl]);
+                acc[cl] = fmaf(v.y, wv.y, acc[cl]);
+                acc[cl] = fmaf(v.z, wv.z, acc[cl]);
+                acc[cl] = fmaf(v.w, wv.w, acc[cl]);
+            }
+        }
+#pragma unroll
+        for (int cl = 0; cl < 5; ++cl) {
+            acc[cl] += __shfl_xor(acc[cl], 1);
+            acc[cl] += __shfl_xor(acc[cl], 2);
+            acc[cl] += __shfl_xor(acc[cl], 32);
+            acc[cl] += bv[cl];
+        }
+        const int win = tile * kTileWin + 2 * g + q;
+        if (c4 == 0 && hi == 0 && win < B) {
+            float res[5];
+            if (normalise) {
+                float mx = acc[0];
+#pragma unroll
+                for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, acc[cl]);
+                float sum = 0.f;
+#pragma unroll
+                for (int cl = 0; cl < 5; ++cl) { res[cl] = __expf(acc[cl] - mx); sum += res[cl]; }
+#pragma unroll
+                for (int cl = 0; cl < 5; ++cl) res[cl] = res[cl] / sum;
+            } else {
+#pragma unroll
+                for (int cl = 0; cl < 5; ++cl) res[cl] = acc[cl];
+            }
+            float *dst = probs + ((size_t)win * T + t) * 5;
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) dst[cl] = res[cl];
         }
     }
 }

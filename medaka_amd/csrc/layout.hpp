@@ -1,0 +1,35 @@
+// HBM layouts of the intermediates (DESIGN.md "data layout").
+//
+// Windows are grouped in tiles of 8.  Both intermediates are stored tile-major and, inside a
+// (tile, t) block, in the register order of the recurrence kernel, so that every wave-level
+// load/store of the serial kernel is one contiguous 256-byte run (the natural [window][t][f]
+// layout made each of them four 64-byte runs 15 MB apart, and the kernel was bound by the number
+// of cache lines its vector-memory instructions touched, not by bytes):
+//
+//   gi_t  [dir][tile][t][w8 8][q 2][gate 3][lane 64]   fp32   3072 floats = 12 KB per block
+//   act_t [tile][t][dir][w8 8][q 2][lane 64]            fp32   D*1024 floats per block
+//
+// with  lane = g*16 + c,  window-in-tile = 2*g + q,  hidden unit = 16*w8 + c.
+// Feature f of an activation row (f = dir*128 + unit) lives in chunk f>>4 = dir*8 + w8.
+#pragma once
+#include <stddef.h>
+
+namespace mdk {
+
+constexpr int kTileWin = 8;          // windows per tile
+constexpr int kGiBlock = 8 * 2 * 3 * 64;   // floats per (dir, tile, t) block of gi_t
+
+__host__ __device__ inline size_t gi_block(int dir, int n_tiles, int tile, int T, int t) {
+    return (((size_t)dir * n_tiles + tile) * T + t) * kGiBlock;
+}
+__host__ __device__ inline int gi_in_block(int w8, int q, int gate, int lane) {
+    return ((w8 * 2 + q) * 3 + gate) * 64 + lane;
+}
+__host__ __device__ inline size_t act_block(int D, int tile, int T, int t) {
+    return ((size_t)tile * T + t) * (size_t)(D * 1024);
+}
+__host__ __device__ inline int act_in_block(int dir, int w8, int q, int lane) {
+    return ((dir * 8 + w8) * 2 + q) * 64 + lane;
+}
+
+}  // namespace mdk

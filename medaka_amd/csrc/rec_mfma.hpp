@@ -6,193 +6,206 @@
 // reference medaka/architectures/gru.py:66) for a tile of 8 windows per work-group.
 //
 // MI355X mapping (DESIGN.md section "recurrence kernel"):
-//   * one 256-thread work-group (4 waves, one per SIMD) per (8-window tile, direction);
-//     wave w owns hidden units [32w, 32w+32) of all three gates = 6 MFMA column tiles;
+//   * one 512-thread work-group (8 waves, two per SIMD) per (8-window tile, direction);
+//     wave w8 owns hidden units [16*w8, 16*w8+16) of all three gates = 3 MFMA column tiles;
 //   * W_hh lives in registers for the whole kernel as pre-packed fp16 hi/lo B-fragments
-//     (192 VGPR/AGPR per lane); h_t is staged in LDS as the fp16 hi/lo A-operand (4.25 KB,
-//     double buffered) -- zero global-memory round trips on the step-to-step dependency;
+//     (96 VGPRs per lane); h_t is staged in LDS as the fp16 hi/lo A-operand (4.25 KB, double
+//     buffered) -- zero global-memory round trips on the step-to-step dependency;
 //   * fp32 parity through an fp16x2 split: A rows = (window, hi|lo) -> 16 rows for 8 windows,
-//     B = W_hi then W_lo into the same fp32 accumulator, so  acc[row hi] + acc[row lo]
+//     B = W_hi then W_lo into fp32 accumulators, so  acc[row hi] + acc[row lo]
 //     = (h_hi + h_lo)(W_hi + W_lo) = h W to ~2^-22 relative, fp32 accumulate;
 //   * sigmoid/tanh, the z-blend, the fp16 re-split and the store of h_t are fused behind the
-//     MFMAs; gi (input projection, bias folded) is prefetched PF steps ahead into registers.
+//     MFMAs; gi (input projection, bias folded, pre-scaled) is prefetched PF steps ahead.
 #pragma once
 #include "common.hpp"
+#include "layout.hpp"
 
 namespace mdk {
 
-constexpr int kRecSeqs = 8;                 // windows per work-group
 constexpr int kHGroupStride = 272;          // bytes: 16 rows x 16 B + 16 B pad (bank spread)
 constexpr int kHKStride = 4 * kHGroupStride;  // one k-step (32 units) of the A image
 constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 
-// Element i of lane-group gq in k-step ks stands for hidden unit (see pack_whh_frags()):
-__host__ __device__ inline int rec_unit_of_slot(int ks, int gq, int i) {
-    return 32 * ks + 16 * (i & 1) + 4 * gq + (i >> 1);
-}
-
-template <int PF>
-__global__ __launch_bounds__(256, 1) void k_rec_mfma(
-    const float *__restrict__ gi,      // [D][M][384] fp32, b_ih (+ b_hh for r,z) folded in
-    const half8 *__restrict__ wfrag,   // [D][4 waves][6 tiles][4 ksteps][2 hi/lo][64 lanes]
-    const float *__restrict__ b_hn,    // [D][128]
-    float *__restrict__ out,           // [M][out_stride]; this direction at column d*128
-    int B, int T, int out_stride, size_t gi_dir_stride, const float *__restrict__ inv_scale_p,
-    int reverse_mask)
+// Why 8 waves: measured on MI355X, a 4-wave version (one wave per SIMD, 6 tiles per wave) is
+// instruction-ISSUE bound (~250 instructions x ~4 cycles per step) -- removing all of its MFMAs
+// shortened the step by only 3 %.  Two waves per SIMD double the issue rate and let one wave's
+// gate math run while the other is blocked on the matrix pipe (8.3 -> 6.6 ms per launch).
+// The arithmetic stays in the scaled domain of the accumulator: gi and b_hn arrive multiplied by
+// S = 2^10 * w_scale and 1/S is folded into the exp2 argument constants.
+// ABL: timing-only ablation mask (1 no MFMA, 2 no gate math, 4 no barrier, 8 no gi loads,
+// 16 no stores); results are garbage unless ABL == 0.
+//   wave w8 owns hidden units [16*w8, 16*w8+16) of the three gates = 3 MFMA column tiles;
+//   W_hh fragments: 96 registers per lane; 2 hidden values per lane per step.
+// Fragment layout [D][8 waves][4 ksteps][3 gates][2 hi/lo][64 lanes], natural k order
+// (slot (ks, lane-group gq, i) = unit 32*ks + 8*gq + i).
+// NQ = windows per lane (1 or 2): a work-group carries 4*NQ windows.  NQ = 1 leaves half of the
+// MFMA rows zero -- free, the matrix pipe is not the limiter -- and halves the per-step VALU and
+// memory instruction count; it is used whenever 4-window tiles still fit the chip in one wave of
+// work-groups (B <= ~500).
+template <int PF, int NQ, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void k_rec_mfma(
+    const float *__restrict__ gi,      // gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
+    const half8 *__restrict__ wfrag,   // [D][8][4][3][2][64]
+    const float *__restrict__ b_hn,    // [D][128]  (unscaled)
+    float *__restrict__ out,           // act_t (layout.hpp)
+    int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = blockIdx.y;
-    const int c = lane & 15;   // MFMA column = unit within tile
-    const int g = lane >> 4;   // MFMA row group: rows 4g..4g+3 = windows 2g, 2g+1 (hi, lo)
+    const int c = lane & 15;
+    const int g = lane >> 4;
     const bool reverse = (reverse_mask >> d) & 1;
     const float inv_scale = inv_scale_p[d];
+    const float c_sig = -inv_scale * 1.44269504088896340736f;
+    const float c_tanh = 2.0f * inv_scale * 1.44269504088896340736f;
 
-    // ---- recurrent weights -> registers (once)
-    half8 wf[6][4][2];
+    half8 wf[4][3][2];
     {
-        const half8 *wp = wfrag + ((size_t)(d * 4 + w) * 48) * 64 + lane;
-#pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-                    wf[t6][ks][sp] = wp[(size_t)((t6 * 4 + ks) * 2 + sp) * 64];
-    }
-
-    // ---- h_0 = 0 in both LDS buffers
-    for (int i = tid; i < 2 * kHBufBytes / 4; i += 256) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
-
-    // ---- per-lane bookkeeping: 2 windows (q) x 2 sub-tiles (s) = 4 hidden values per lane
-    const int seq_base = blockIdx.x * kRecSeqs + 2 * g;
-    int u[2];
-    float bhn[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u[s] = 32 * w + 16 * s + c;
-        bhn[s] = b_hn[d * kH + u[s]];
-    }
-    bool valid[2];
-    size_t row0[2];   // first row (t = 0) of window q in the [M] dimension
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int sq = seq_base + q;
-        valid[q] = sq < B;
-        if (sq >= B) sq = B - 1;
-        row0[q] = (size_t)sq * T;
-    }
-    const float *gi_d = gi + (size_t)d * gi_dir_stride;
-    float hprev[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-
-    // gi prefetch ring: gq[p][(s*2+q)*3 + gate]
-    float gq[PF][12];
-    auto load_gi = [&](int step, float (&dst)[12]) {
-        if (step >= T) step = T - 1;
-        const int t = reverse ? (T - 1 - step) : step;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float *p = gi_d + (row0[q] + t) * kG + u[s];
-#pragma unroll
-                for (int gate = 0; gate < 3; ++gate)
-                    dst[(s * 2 + q) * 3 + gate] = p[gate * kH];
-            }
-    };
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) gq[p][i] = 0.f;
-
-    // LDS addressing (bytes)
-    const int rd_off = g * kHGroupStride + c * 16;                          // + ks*kHKStride
-    const int wr_off = w * kHKStride + (c >> 2) * kHGroupStride + (4 * g) * 16 + (c & 3) * 4;
-
-    // Pin every loop-invariant global load (weights, b_hn) as complete BEFORE the loop: an empty
-    // asm use makes hipcc wait for the value here.  Otherwise its waitcnt pass carries them as
-    // "possibly pending" around the back edge and emits vmcnt(0) at their first use in every
-    // iteration -- one exposed HBM round trip per step.
-#pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6)
+        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * 24) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[t6][ks][sp]));
-    asm volatile("" ::"v"(bhn[0]), "v"(bhn[1]));
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+                    wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
+    }
+    for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+
+    const int u = 16 * w8 + c;
+    const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
+    // which windows of which tile: NQ == 2 -> the whole tile (window 2g+q);
+    // NQ == 1 -> half tile h: window 4h + g, i.e. layout lane-group 2h + (g>>1), q = g&1
+    const int tile = (NQ == 2) ? blockIdx.x : (blockIdx.x >> 1);
+    const long tstep = reverse ? -1 : 1;
+    const int t_first = reverse ? (T - 1) : 0;
+    const float *gp[NQ];
+    float *op[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int lq, llane;
+        if (NQ == 2) { lq = q; llane = lane; }
+        else { const int h = blockIdx.x & 1; lq = g & 1; llane = (2 * h + (g >> 1)) * 16 + c; }
+        gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first) + gi_in_block(w8, lq, 0, llane);
+        op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, lq, llane);
+    }
+    const long gstride = tstep * kGiBlock;
+    const long ostride = tstep * (long)(D * 1024);
+    float hprev[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) hprev[q] = 0.f;
+
+    // rows of the A operand: 4g + 2q + {0: hi, 1: lo}; with NQ == 1 rows 4g+2, 4g+3 stay zero.
+    // gi prefetch ring, PF steps deep: gq[p][q*3 + gate].  Primed here and fully drained once
+    // (one HBM round trip per launch): the main loop is then entered with nothing in flight, so
+    // hipcc's waitcnt pass sees the ring only in its steady-state issue order and emits counted
+    // vmcnt(N >> 0) waits.  (A peeled / reordered priming sequence makes it emit vmcnt(~0) in
+    // the first unrolled step of EVERY iteration = one exposed HBM latency per PF steps.)
+    float gq[PF][3 * NQ];
+    auto refill = [&](float (&dst)[3 * NQ], bool advance) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                if constexpr (!(ABL & 8)) dst[q * 3 + gate] = gp[q][gate * 64]; else dst[q * 3 + gate] = 0.f;
+            if (advance) gp[q] += gstride;   // stop advancing at the last row
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) refill(gq[p], p + 1 < T);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int i = 0; i < 3 * NQ; ++i) asm volatile("" ::"v"(gq[p][i]));
+
+    const int rd_off = g * kHGroupStride + c * 16;
+    const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
+                       (4 * g) * 16 + (c & 7) * 2;
+
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
+    asm volatile("" ::"v"(bhn));
     __syncthreads();
 
-    // The ring is primed by running the loop from step -PF with the compute skipped: every gi
-    // load is issued from one static site per ring slot, unconditionally and in ring order, which
-    // lets hipcc's waitcnt pass emit counted vmcnt(N>0) waits (a separate prologue, or a load
-    // under the step branch, degrades to vmcnt(0) = one HBM round trip per step).
-    for (int step0 = -PF; step0 < T; step0 += PF) {
+    for (int step0 = 0; step0 < T; step0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int step = step0 + p;
-            if (step >= 0 && step < T) {   // wave-uniform
+            if (step < T) {   // wave-uniform
                 const int cur = (step & 1) * kHBufBytes;
                 const int nxt = kHBufBytes - cur;
-                const int t = reverse ? (T - 1 - step) : step;
 
-                // 1. A operand: h_{t-1} as fp16 (hi, lo) rows, all 128 units
                 half8 a[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
 
-                // 2. gh = h W_hh^T on the matrix core (sub-tile 0 first so that its gate math
-                //    can overlap the MFMAs of sub-tile 1)
-                floatx4 acc[6];
+                floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar;
+                if constexpr (ABL & 1) {
 #pragma unroll
-                for (int t6 = 0; t6 < 6; ++t6) acc[t6] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ar[ks] = (float)a[ks][0]; az[ks] = (float)a[ks][2];
+                        anh[ks] = (float)a[ks][4]; anl[ks] = (float)a[ks][6];
+                    }
+                } else {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int gate = 0; gate < 3; ++gate) {
-                            const int t6 = s * 3 + gate;
-                            acc[t6] = mfma16(a[ks], wf[t6][ks][0], acc[t6]);
-                            acc[t6] = mfma16(a[ks], wf[t6][ks][1], acc[t6]);
-                        }
-
-                // 3. gates, blend, store, re-split into the other LDS buffer
-                float hn[2][2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float gh_r = (acc[s * 3 + 0][2 * q] + acc[s * 3 + 0][2 * q + 1]) * inv_scale;
-                        const float gh_z = (acc[s * 3 + 1][2 * q] + acc[s * 3 + 1][2 * q + 1]) * inv_scale;
-                        const float gh_n = (acc[s * 3 + 2][2 * q] + acc[s * 3 + 2][2 * q + 1]) * inv_scale;
-                        const float *gv = &gq[p][(s * 2 + q) * 3];
-                        const float r = sigmoid_f(gv[0] + gh_r);
-                        const float z = sigmoid_f(gv[1] + gh_z);
-                        const float n = tanh_f(gv[2] + r * (gh_n + bhn[s]));
-                        const float h = n + z * (hprev[s][q] - n);
-                        hprev[s][q] = h;
-                        hn[s][q] = h;
-                        if (valid[q]) out[(row0[q] + t) * out_stride + d * kH + u[s]] = h;
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ar = mfma16(a[ks], wf[ks][0][0], ar);
+                        az = mfma16(a[ks], wf[ks][1][0], az);
+                        ar = mfma16(a[ks], wf[ks][0][1], ar);
+                        az = mfma16(a[ks], wf[ks][1][1], az);
                     }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    _Float16 hi0, lo0, hi1, lo1;
-                    split_f16(hn[0][q] * kActScale, hi0, lo0);
-                    split_f16(hn[1][q] * kActScale, hi1, lo1);
-                    half2_t vhi = {hi0, hi1};
-                    half2_t vlo = {lo0, lo1};
-                    *reinterpret_cast<half2_t *>(hbuf + nxt + wr_off + (2 * q) * 16) = vhi;
-                    *reinterpret_cast<half2_t *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = vlo;
+                    for (int ks = 0; ks < 4; ++ks) {
+                        anh = mfma16(a[ks], wf[ks][2][0], anh);
+                        anl = mfma16(a[ks], wf[ks][2][1], anl);
+                    }
                 }
+                float hn[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float *gv = &gq[p][q * 3];
+                    if constexpr (ABL & 2) {
+                        const float h = ((ar[2 * q] + az[2 * q + 1]) + (anh[2 * q] + anl[2 * q + 1])) * 1e-6f +
+                                        (gv[0] + gv[1] + gv[2]) * 1e-9f;
+                        hprev[q] = h; hn[q] = h;
+                        if constexpr (!(ABL & 16)) op[q][0] = h;
+                        continue;
+                    }
+                    const float tr = (gv[0] + ar[2 * q]) + ar[2 * q + 1];
+                    const float tz = (gv[1] + az[2 * q]) + az[2 * q + 1];
+                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+                    const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                    const float an = __builtin_fmaf(r, tn, gv[2]);
+                    const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                    const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                    const float h = __builtin_fmaf(z, hprev[q] - n, n);
+                    hprev[q] = h;
+                    hn[q] = h;
+                    if constexpr (!(ABL & 16)) op[q][0] = h;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    _Float16 hi, lo;
+                    split_f16(hn[q] * kActScale, hi, lo);
+                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                    op[q] += ostride;
+                }
+                if constexpr (ABL & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();
             }
-            // 4. refill this ring slot PF steps ahead -- unconditionally, so that every path
-            //    through the unrolled body issues the same loads in the same order
-            load_gi(step + PF, gq[p]);
+            // refill ring slot p for step + PF: unconditional and in ring order on every path
+            refill(gq[p], (step + PF + 1) < T);
         }
     }
 }

@@ -90,11 +90,15 @@ class GruEngine:
     def set_precision(self, half):
         _lib.check(_lib.load().mdk_gru_set_precision(self._h, 1 if half else 0), "mdk_gru_set_precision")
 
-    def set_variant(self, exact):
-        _lib.check(_lib.load().mdk_gru_set_variant(self._h, 1 if exact else 0), "mdk_gru_set_variant")
+    def set_variant(self, variant):
+        """0 / False: MFMA kernels, 1 / True: exact fp32 kernels, 2: first-generation MFMA kernel."""
+        _lib.check(_lib.load().mdk_gru_set_variant(self._h, int(variant)), "mdk_gru_set_variant")
 
     def set_normalise(self, normalise):
         _lib.check(_lib.load().mdk_gru_set_normalise(self._h, int(bool(normalise))), "mdk_gru_set_normalise")
+
+    def set_option(self, key, value):
+        _lib.check(_lib.load().mdk_gru_set_option(self._h, key.encode(), int(value)), "mdk_gru_set_option")
 
     def enable_timing(self, on=True):
         _lib.check(_lib.load().mdk_gru_enable_timing(self._h, int(on)), "mdk_gru_enable_timing")

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmedaka_amd.so")
+LIB_PATH = os.environ.get("MDK_LIB") or os.path.join(_HERE, "libmedaka_amd.so")
 
 MDK_OK, MDK_ERR_ARG, MDK_ERR_DEVICE, MDK_ERR_OOM = 0, 1, 2, 3
 MDK_PREC_FP32, MDK_PREC_FP16 = 0, 1
@@ -38,6 +38,7 @@ ABI = {
     "mdk_gru_set_precision": (_i, [_vp, _i]),
     "mdk_gru_set_variant": (_i, [_vp, _i]),
     "mdk_gru_set_normalise": (_i, [_vp, _i]),
+    "mdk_gru_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_device": (_i, [_vp]),

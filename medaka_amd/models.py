@@ -126,6 +126,7 @@ class GRUModel(CountsMatrixModel):
         self._engine = None
         self._engine_key = None
         self.exact_kernels = False   # MDK_VARIANT_EXACT (debug cross-check kernels)
+        self.kernel_variant = None   # explicit MDK_VARIANT_* override (A/B timing)
 
     # -- engine life cycle -----------------------------------------------------------------
     def _state_key(self, dev_index):
@@ -146,7 +147,8 @@ class GRUModel(CountsMatrixModel):
                 normalise=bool(self.normalise), device=dev_index)
             self._engine_key = key
         self._engine.set_precision(self.half_precision)
-        self._engine.set_variant(self.exact_kernels)
+        self._engine.set_variant(self.kernel_variant if self.kernel_variant is not None
+                                 else int(self.exact_kernels))
         self._engine.set_normalise(bool(self.normalise))
         return self._engine
 

@@ -103,6 +103,19 @@ def test_exact_and_mfma_kernels_agree_on_device(gold, engines):
     assert np.abs(a - b).max() <= TOL
 
 
+def test_both_tile_sizes_agree_bitwise(gold):
+    """4-window and 8-window recurrence tiles run the same arithmetic per window."""
+    x = synth.counts_windows(21, 500, seed=31)
+    outs = []
+    for tile in (4, 8):
+        e = engine.GruEngine(weight_set(gold, "x3"))
+        e.set_option("rec_windows_per_tile", tile)
+        outs.append(e.forward_host(x))
+        e.close()
+    assert np.array_equal(outs[0], outs[1])
+    _check(outs[1], oracle.c_gru_forward(x, weight_set(gold, "x3")), what="8-window tiles")
+
+
 def test_empty_inputs(gold, engines):
     e = engines("init")
     assert e.forward_host(np.zeros((0, 10, 10), np.float32)).shape == (0, 10, 5)
