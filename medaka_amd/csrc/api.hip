@@ -64,8 +64,10 @@ struct LayerDev {
     float *b_hn = nullptr;        // [D][128]
     half8 *whh_frag = nullptr;    // [D][8 waves][4 ks][3 gates][2 hi/lo][64 lanes]
     float *ones = nullptr;        // [D] = 1
+    half8 *wx_frag = nullptr;     // layer 0 only: fused input projection B-fragments [D][8][3][2][64]
+    float x_scale = 0.f;          // layer 0 only: sx (0 = fusion unavailable)
     float *up_scale_rec = nullptr;   // [D] = 1/inv_scale_rec
-    half8 *wih_frag = nullptr;    // [D][2][4][K/32][3][2][64] (layers >= 1)
+    half8 *wih_frag = nullptr;    // [D][8 waves][K/32][3 gates][2][64] (layers >= 1)
     float *inv_scale_rec = nullptr;  // [D]
     float *inv_scale_gi = nullptr;   // [D]
 };
@@ -78,6 +80,10 @@ struct mdk_gru {
     int variant = MDK_VARIANT_MFMA;
     int opt_tile_windows = 0;   // 0 auto, 4, 8
     int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
+    int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
+    half8 *xfrag = nullptr;     // packed layer-0 input fragments
+    size_t xfrag_cap = 0;
+    int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
     std::vector<LayerDev> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace (grown on demand)
@@ -101,10 +107,10 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     (void)hipSetDevice(m->device);
     for (auto &L : m->layers) {
         free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
-        free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
+        free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.wx_frag); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
-    free_dev(m->x_dev); free_dev(m->p_dev);
+    free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -208,24 +214,23 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
             if (l > 0) {
                 const float swi = pick_scale(w_ih, (size_t)kG * K);
                 inv_gi[d] = 1.0f / (kActScale * swi);
-                for (int nhalf = 0; nhalf < 2; ++nhalf)
-                    for (int w = 0; w < 4; ++w)
-                        for (int ks = 0; ks < KS; ++ks)
-                            for (int nt = 0; nt < 3; ++nt)
-                                for (int lane = 0; lane < 64; ++lane) {
-                                    const int col = nt * kH + 16 * (4 * nhalf + w) + (lane & 15);   // gate nt, unit
-                                    const int gq = lane >> 4;
-                                    half8 hi, lo;
-                                    for (int i = 0; i < 8; ++i) {
-                                        const int k = 32 * ks + 8 * gq + i;
-                                        _Float16 a, b;
-                                        split_host(w_ih[(size_t)col * K + k] * swi, a, b);
-                                        hi[i] = a; lo[i] = b;
-                                    }
-                                    const size_t base = (((((size_t)((d * 2 + nhalf) * 4 + w)) * KS + ks) * 3 + nt) * 2) * 64 + lane;
-                                    wih_frag[base] = hi;
-                                    wih_frag[base + 64] = lo;
+                for (int w8 = 0; w8 < 8; ++w8)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int nt = 0; nt < 3; ++nt)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int col = nt * kH + 16 * w8 + (lane & 15);   // gate nt, unit
+                                const int gq = lane >> 4;
+                                half8 hi, lo;
+                                for (int i = 0; i < 8; ++i) {
+                                    const int k = 32 * ks + 8 * gq + i;
+                                    _Float16 a, b;
+                                    split_host(w_ih[(size_t)col * K + k] * swi, a, b);
+                                    hi[i] = a; lo[i] = b;
                                 }
+                                const size_t base = (((((size_t)(d * 8 + w8)) * KS + ks) * 3 + nt) * 2) * 64 + lane;
+                                wih_frag[base] = hi;
+                                wih_frag[base + 64] = lo;
+                            }
             } else {
                 inv_gi[d] = 1.0f;
             }
@@ -240,7 +245,49 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         if (l > 0 && (rc = upload(&Ld.wih_frag, wih_frag))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_rec, inv_rec))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_gi, inv_gi))) return bail(rc);
+        if (l == 0 && K + 1 <= 32) {
+            // fused layer-0 projection: one sx for all directions (the packed x is shared),
+            // per-direction W_ih scale swx = S_d / sx
+            float sx = 16.0f;
+            for (int d = 0; d < D; ++d) {
+                const float *w_ih = weights[4 * d + 0];
+                float mx = 0.f;
+                for (size_t i = 0; i < (size_t)kG * K; ++i) mx = std::max(mx, std::fabs(w_ih[i]));
+                for (int j = 0; j < kG; ++j) mx = std::max(mx, std::fabs(bias_gi[(size_t)d * kG + j]));
+                const float need = up_rec[d] * mx / 32768.0f;   // sx >= S * max / 2^15
+                while (sx < need) sx *= 2.0f;
+            }
+            if (sx <= 8192.0f) {
+                std::vector<half8> wx((size_t)D * 8 * 3 * 2 * 64);
+                for (int d = 0; d < D; ++d) {
+                    const float *w_ih = weights[4 * d + 0];
+                    const float swx = up_rec[d] / sx;
+                    for (int w8 = 0; w8 < 8; ++w8)
+                        for (int gate = 0; gate < 3; ++gate)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int j = gate * kH + 16 * w8 + (lane & 15);
+                                const int gq = lane >> 4;
+                                half8 hi, lo;
+                                for (int i = 0; i < 8; ++i) {
+                                    const int f = 8 * gq + i;
+                                    float v = 0.f;
+                                    if (f < K) v = w_ih[(size_t)j * K + f] * swx;
+                                    else if (f == K) v = bias_gi[(size_t)d * kG + j] * swx;
+                                    _Float16 a, b;
+                                    split_host(v, a, b);
+                                    hi[i] = a; lo[i] = b;
+                                }
+                                const size_t base = ((((size_t)(d * 8 + w8)) * 3 + gate) * 2) * 64 + lane;
+                                wx[base] = hi;
+                                wx[base + 64] = lo;
+                            }
+                }
+                if ((rc = upload(&Ld.wx_frag, wx))) return bail(rc);
+                Ld.x_scale = sx;
+            }
+        }
     }
+    if (hipMalloc((void **)&m->oor_flag, sizeof(int)) != hipSuccess) return bail(fail(MDK_ERR_OOM, "hipMalloc failed"));
     {
         std::vector<float> lw(weights[4 * L * D], weights[4 * L * D] + (size_t)C * D * H);
         std::vector<float> lb(weights[4 * L * D + 1], weights[4 * L * D + 1] + C);
@@ -279,6 +326,8 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_tile_windows = value;
     } else if (!strcmp(key, "ablate")) {
         m->opt_ablate = value;
+    } else if (!strcmp(key, "fuse_l0")) {
+        m->opt_fuse_l0 = value ? 1 : 0;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -382,61 +431,85 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // ---- production path: tile-major intermediates (layout.hpp)
     if (m->layers[0].K > 16)
         return fail(MDK_ERR_ARG, "num_features %d > 16 is only supported by MDK_VARIANT_EXACT", m->layers[0].K);
+    // "ablate" option / MDK_ABLATE=<mask>: timing-only ablations (wrong results)
+    static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
+    const int abl = m->opt_ablate ? m->opt_ablate : env_abl;
+    // half-tile (4-window) work-groups while they fit the chip in one round, else whole tiles
+    int nq = (2 * n_tiles) * D <= 256 ? 1 : 2;
+    if (m->opt_tile_windows == 4) nq = 1;
+    if (m->opt_tile_windows == 8) nq = 2;
+    const int n_wg = nq == 1 ? 2 * n_tiles : n_tiles;
+    const dim3 rgrid(n_wg, D);
+
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
+        const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr;
+        const int *cond = fuse ? m->oor_flag : nullptr;
         if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
+        if (fuse) {
+            const size_t need = (size_t)n_wg * T * 64;
+            if (need > m->xfrag_cap) {
+                free_dev(m->xfrag); m->xfrag = nullptr; m->xfrag_cap = 0;
+                HIP_TRY(hipMalloc((void **)&m->xfrag, need * sizeof(half8)));
+                m->xfrag_cap = need;
+            }
+            HIP_TRY(hipMemsetAsync(m->oor_flag, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, in, m->xfrag, nb, T,
+                               Ld.K, nq, n_wg, Ld.x_scale, m->oor_flag);
+        }
         if (l == 0) {
+            // unfused layer-0 projection: the only path without fusion, the on-device fallback
+            // (input beyond fp16 range) with it
             const int tpb = 128;
             hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, in,
-                               Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec);
+                               Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec, cond, 1);
         } else {
             const dim3 grid((T + kGemmSteps - 1) / kGemmSteps, n_tiles);
             if (D == 2)
-                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(256), (size_t)2 * 8 * 8 * 64 * sizeof(half8), s, in,
+                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(512), (size_t)2 * 8 * 8 * 64 * sizeof(half8), s, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
                                    Ld.up_scale_rec);
             else
-                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(256), (size_t)2 * 8 * 4 * 64 * sizeof(half8), s, in,
+                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(512), (size_t)2 * 8 * 4 * 64 * sizeof(half8), s, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
                                    Ld.up_scale_rec);
         }
         if ((rc = tm.end())) return rc;
         if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
-        {
-            // "ablate" option / MDK_ABLATE=<mask>: timing-only ablations (wrong results)
-            static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
-            const int abl = m->opt_ablate ? m->opt_ablate : env_abl;
-            // half-tile (4-window) work-groups while they fit the chip in one round, else whole tiles
-            int nq = (2 * n_tiles) * D <= 256 ? 1 : 2;
-            if (m->opt_tile_windows == 4) nq = 1;
-            if (m->opt_tile_windows == 8) nq = 2;
-            const dim3 grid(nq == 1 ? 2 * n_tiles : n_tiles, D);
-#define MDK_LAUNCH_REC(A)                                                                          \
+#define MDK_REC_ARGS(XIN, CND, WANT)                                                               \
+    m->gi, m->xfrag, Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,     \
+        reverse_mask, CND, WANT
+#define MDK_LAUNCH_REC(XIN, A, CND, WANT)                                                          \
     do {                                                                                           \
         if (nq == 1)                                                                               \
-            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 1, A>), grid, dim3(512), 0, s, m->gi, Ld.whh_frag, \
-                               Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, reverse_mask);      \
+            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 1, XIN, A>), rgrid, dim3(512), 0, s,            \
+                               MDK_REC_ARGS(XIN, CND, WANT));                                      \
         else                                                                                       \
-            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 2, A>), grid, dim3(512), 0, s, m->gi, Ld.whh_frag, \
-                               Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, reverse_mask);      \
+            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 2, XIN, A>), rgrid, dim3(512), 0, s,            \
+                               MDK_REC_ARGS(XIN, CND, WANT));                                      \
     } while (0)
-            switch (abl) {
-                case 0: MDK_LAUNCH_REC(0); break;
-                case 1: MDK_LAUNCH_REC(1); break;
-                case 2: MDK_LAUNCH_REC(2); break;
-                case 3: MDK_LAUNCH_REC(3); break;
-                case 4: MDK_LAUNCH_REC(4); break;
-                case 7: MDK_LAUNCH_REC(7); break;
-                case 8: MDK_LAUNCH_REC(8); break;
-                case 15: MDK_LAUNCH_REC(15); break;
-                case 16: MDK_LAUNCH_REC(16); break;
-                case 24: MDK_LAUNCH_REC(24); break;
-                case 31: MDK_LAUNCH_REC(31); break;
-                default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
-            }
-#undef MDK_LAUNCH_REC
+#define MDK_LAUNCH_REC_ABL(XIN, CND, WANT)                                                         \
+    switch (abl) {                                                                                 \
+        case 0: MDK_LAUNCH_REC(XIN, 0, CND, WANT); break;                                          \
+        case 1: MDK_LAUNCH_REC(XIN, 1, CND, WANT); break;                                          \
+        case 2: MDK_LAUNCH_REC(XIN, 2, CND, WANT); break;                                          \
+        case 4: MDK_LAUNCH_REC(XIN, 4, CND, WANT); break;                                          \
+        case 8: MDK_LAUNCH_REC(XIN, 8, CND, WANT); break;                                          \
+        case 16: MDK_LAUNCH_REC(XIN, 16, CND, WANT); break;                                        \
+        case 7: MDK_LAUNCH_REC(XIN, 7, CND, WANT); break;                                          \
+        case 31: MDK_LAUNCH_REC(XIN, 31, CND, WANT); break;                                        \
+        default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);                    \
+    }
+        if (fuse) {
+            MDK_LAUNCH_REC_ABL(true, cond, 0);    // fused: runs unless the range flag is up
+            MDK_LAUNCH_REC(false, 0, cond, 1);    // fallback on the flag
+        } else {
+            MDK_LAUNCH_REC_ABL(false, nullptr, 0);
         }
+#undef MDK_LAUNCH_REC_ABL
+#undef MDK_LAUNCH_REC
+#undef MDK_REC_ARGS
         if ((rc = tm.end())) return rc;
         m->last.rec_launches++;
         in = outp;

@@ -28,8 +28,10 @@ __global__ __launch_bounds__(768) void k_gi_small(
     const float *__restrict__ w_ih_t, // [D][K][384]  (transposed at load time)
     const float *__restrict__ bias,   // [D][384]     folded bias
     float *__restrict__ gi,           // gi_t
-    int B, int T, int K, int n_tiles, int t_per_block, const float *__restrict__ out_scale_p)
+    int B, int T, int K, int n_tiles, int t_per_block, const float *__restrict__ out_scale_p,
+    const int *__restrict__ cond, int want)
 {
+    if (cond != nullptr && ((*cond != 0) != (want != 0))) return;   // see k_pack_x
     const int tile = blockIdx.x;
     const int d = blockIdx.y;
     const float os = out_scale_p[d];
@@ -70,20 +72,21 @@ __global__ __launch_bounds__(768) void k_gi_small(
 }
 
 // ------------------------------------------------------------------------------------------
-// layers >= 1.  Work-group = 4 waves, M-tile = one window tile x 16 time steps = 128 rows, read
-// as ONE contiguous run of 16 activation blocks.  MFMA row 4g + 2q + tt of row-tile mt is
+// layers >= 1.  Work-group = 8 waves (2 per SIMD: the 4-wave version was instruction-issue
+// bound, matrix pipe 31 % busy), M-tile = one window tile x 16 time steps = 128 rows, read as ONE
+// contiguous run of 16 activation blocks.  MFMA row 4g + 2q + tt of row-tile mt is
 // (window 2g+q, t0 + 2*mt + tt), so accumulator register r = 2q + tt of lane g*16+c is exactly
 // element `lane` of gi block t0+2mt+tt, sub-block (w8, q, gate): every accumulator register is
 // stored by the wave as one contiguous 256-byte run.  The x tile is converted once to fp16
 // hi/lo A-fragments in LDS (128 KB at K = 256); W_ih B-fragments stream from L2, pre-packed so
-// that each lane issues one 16-byte load per fragment.  2*D passes (direction, unit half ph):
-// wave w owns units 16*(4*ph + w) .. +15 of all three gates.
+// that each lane issues one 16-byte load per fragment.  One pass per output direction: wave w8
+// owns hidden units 16*w8 .. +15 of all three gates (24 accumulator tiles).
 constexpr int kGemmSteps = 16;
 
 template <int KSTEPS>   // K = 32 * KSTEPS = D_in * 128
-__global__ __launch_bounds__(256, 1) void k_gi_gemm(
+__global__ __launch_bounds__(512, 2) void k_gi_gemm(
     const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
-    const half8 *__restrict__ wfrag,   // [D][2 ph][4 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
+    const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
     const float *__restrict__ bias,    // [D][384]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
@@ -96,14 +99,14 @@ __global__ __launch_bounds__(256, 1) void k_gi_gemm(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.y;
     const int t0 = blockIdx.x * kGemmSteps;
 
     // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)
     {
         const float *src0 = act_in + act_block(DIN, tile, T, t0);
-        for (int P = tid; P < kGemmSteps * NP; P += 256) {
+        for (int P = tid; P < kGemmSteps * NP; P += 512) {
             const int tau = P / NP, j = P % NP;
             const int g = j & 3, q = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
             const int piece = chunk * 16 + q * 8 + g * 2 + half;
@@ -134,17 +137,14 @@ __global__ __launch_bounds__(256, 1) void k_gi_gemm(
     }
     __syncthreads();
 
-    const int g = lane >> 4;
-    for (int pass = 0; pass < 2 * D; ++pass) {
-        const int d = pass >> 1, ph = pass & 1;
-        const int w8 = 4 * ph + w;
+    for (int d = 0; d < D; ++d) {
         floatx4 acc[8][3];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-        const half8 *wp = wfrag + ((size_t)(pass * 4 + w) * KSTEPS) * 6 * 64 + lane;
+        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
 #pragma unroll 1
         for (int ks = 0; ks < KSTEPS; ++ks) {
             half8 bh[3], bl[3];
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256, 1) void k_gi_gemm(
             }
         }
     }
-    (void)g;
 }
 
 }  // namespace mdk

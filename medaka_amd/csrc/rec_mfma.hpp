@@ -34,6 +34,7 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // S = 2^10 * w_scale and 1/S is folded into the exp2 argument constants.
 // ABL: timing-only ablation mask (1 no MFMA, 2 no gate math, 4 no barrier, 8 no gi loads,
 // 16 no stores); results are garbage unless ABL == 0.
+// XIN (layer 0): the input projection is fused -- see k_pack_x below.
 //   wave w8 owns hidden units [16*w8, 16*w8+16) of the three gates = 3 MFMA column tiles;
 //   W_hh fragments: 96 registers per lane; 2 hidden values per lane per step.
 // Fragment layout [D][8 waves][4 ksteps][3 gates][2 hi/lo][64 lanes], natural k order
@@ -42,15 +43,20 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // MFMA rows zero -- free, the matrix pipe is not the limiter -- and halves the per-step VALU and
 // memory instruction count; it is used whenever 4-window tiles still fit the chip in one wave of
 // work-groups (B <= ~500).
-template <int PF, int NQ, int ABL = 0>
+template <int PF, int NQ, bool XIN, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
-    const float *__restrict__ gi,      // gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
-    const half8 *__restrict__ wfrag,   // [D][8][4][3][2][64]
+    const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
+    const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
+    const half8 *__restrict__ wxfrag,  //  XIN: W_ih (+bias row) B-fragments [D][8][3][2][64]
+    const half8 *__restrict__ wfrag,   // W_hh B-fragments [D][8][4][3][2][64]
     const float *__restrict__ b_hn,    // [D][128]  (unscaled)
     float *__restrict__ out,           // act_t (layout.hpp)
-    int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask)
+    int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask,
+    const int *__restrict__ cond, int want)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
+    // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
+    if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,6 +80,14 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 for (int sp = 0; sp < 2; ++sp)
                     wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
+    half8 wx[3][2];
+    if constexpr (XIN) {
+        const half8 *wp = wxfrag + ((size_t)(d * 8 + w8) * 6) * 64 + lane;
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) wx[gate][sp] = wp[(size_t)(gate * 2 + sp) * 64];
+    }
     for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
 
     const int u = 16 * w8 + c;
@@ -93,34 +107,51 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first) + gi_in_block(w8, lq, 0, llane);
         op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, lq, llane);
     }
+    const half8 *xp = xfrag + ((size_t)blockIdx.x * T + t_first) * 64 + lane;
     const long gstride = tstep * kGiBlock;
     const long ostride = tstep * (long)(D * 1024);
+    const long xstride = tstep * 64;
     float hprev[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) hprev[q] = 0.f;
 
     // rows of the A operand: 4g + 2q + {0: hi, 1: lo}; with NQ == 1 rows 4g+2, 4g+3 stay zero.
-    // gi prefetch ring, PF steps deep: gq[p][q*3 + gate].  Primed here and fully drained once
-    // (one HBM round trip per launch): the main loop is then entered with nothing in flight, so
-    // hipcc's waitcnt pass sees the ring only in its steady-state issue order and emits counted
-    // vmcnt(N >> 0) waits.  (A peeled / reordered priming sequence makes it emit vmcnt(~0) in
-    // the first unrolled step of EVERY iteration = one exposed HBM latency per PF steps.)
+    // Prefetch ring, PF steps deep: gq[p][q*3 + gate] (or the packed x fragment xq[p]).  Primed
+    // here and fully drained once (one HBM round trip per launch): the main loop is then entered
+    // with nothing in flight, so hipcc's waitcnt pass sees the ring only in its steady-state issue
+    // order and emits counted vmcnt(N >> 0) waits.  (A peeled / reordered priming sequence makes it
+    // emit vmcnt(~0) in the first unrolled step of EVERY iteration = one exposed HBM latency per
+    // PF steps.)
     float gq[PF][3 * NQ];
-    auto refill = [&](float (&dst)[3 * NQ], bool advance) {
+    half8 xq[PF];
+    auto refill = [&](int p, bool advance) {
+        if constexpr (XIN) {
+            if constexpr (!(ABL & 8)) xq[p] = *xp;
+            if (advance) xp += xstride;
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
-                if constexpr (!(ABL & 8)) dst[q * 3 + gate] = gp[q][gate * 64]; else dst[q * 3 + gate] = 0.f;
-            if (advance) gp[q] += gstride;   // stop advancing at the last row
+                for (int gate = 0; gate < 3; ++gate)
+                    if constexpr (!(ABL & 8)) gq[p][q * 3 + gate] = gp[q][gate * 64]; else gq[p][q * 3 + gate] = 0.f;
+                if (advance) gp[q] += gstride;   // stop advancing at the last row
+            }
         }
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) refill(gq[p], p + 1 < T);
+    for (int p = 0; p < PF; ++p) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
+        for (int i = 0; i < 8; ++i) xq[p][i] = (_Float16)0.f;
+        refill(p, p + 1 < T);
+    }
 #pragma unroll
-        for (int i = 0; i < 3 * NQ; ++i) asm volatile("" ::"v"(gq[p][i]));
+    for (int p = 0; p < PF; ++p) {
+        if constexpr (XIN) asm volatile("" ::"v"(xq[p]));
+        else {
+#pragma unroll
+            for (int i = 0; i < 3 * NQ; ++i) asm volatile("" ::"v"(gq[p][i]));
+        }
+    }
 
     const int rd_off = g * kHGroupStride + c * 16;
     const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
@@ -132,6 +163,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
+    if constexpr (XIN) {
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wx[gate][sp]));
+    }
     asm volatile("" ::"v"(bhn));
     __syncthreads();
 
@@ -148,7 +185,17 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 for (int ks = 0; ks < 4; ++ks)
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
 
-                floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar;
+                floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
+                if constexpr (XIN && !(ABL & 1)) {
+                    // layer-0 input projection: independent of h, issued while the LDS reads of h
+                    // are in flight; r and z continue into the same accumulators
+                    ar = mfma16(xq[p], wx[0][0], ar);
+                    az = mfma16(xq[p], wx[1][0], az);
+                    gin = mfma16(xq[p], wx[2][0], gin);
+                    ar = mfma16(xq[p], wx[0][1], ar);
+                    az = mfma16(xq[p], wx[1][1], az);
+                    gin = mfma16(xq[p], wx[2][1], gin);
+                }
                 if constexpr (ABL & 1) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
@@ -172,20 +219,22 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 float hn[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const float *gv = &gq[p][q * 3];
+                    float gr, gz, gn;
+                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gn = gin[2 * q] + gin[2 * q + 1]; }
+                    else { gr = gq[p][q * 3]; gz = gq[p][q * 3 + 1]; gn = gq[p][q * 3 + 2]; }
                     if constexpr (ABL & 2) {
                         const float h = ((ar[2 * q] + az[2 * q + 1]) + (anh[2 * q] + anl[2 * q + 1])) * 1e-6f +
-                                        (gv[0] + gv[1] + gv[2]) * 1e-9f;
+                                        (gr + gz + gn) * 1e-9f;
                         hprev[q] = h; hn[q] = h;
                         if constexpr (!(ABL & 16)) op[q][0] = h;
                         continue;
                     }
-                    const float tr = (gv[0] + ar[2 * q]) + ar[2 * q + 1];
-                    const float tz = (gv[1] + az[2 * q]) + az[2 * q + 1];
+                    const float tr = XIN ? (ar[2 * q] + ar[2 * q + 1]) : ((gr + ar[2 * q]) + ar[2 * q + 1]);
+                    const float tz = XIN ? (az[2 * q] + az[2 * q + 1]) : ((gz + az[2 * q]) + az[2 * q + 1]);
                     const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
                     const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
                     const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                    const float an = __builtin_fmaf(r, tn, gv[2]);
+                    const float an = __builtin_fmaf(r, tn, gn);
                     const float e = __builtin_amdgcn_exp2f(an * c_tanh);
                     const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
                     const float h = __builtin_fmaf(z, hprev[q] - n, n);
@@ -205,9 +254,56 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 lds_barrier();
             }
             // refill ring slot p for step + PF: unconditional and in ring order on every path
-            refill(gq[p], (step + PF + 1) < T);
+            refill(p, (step + PF + 1) < T);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Layer-0 fusion.  The input projection of layer 0 has K = num_features (10): instead of
+// materialising gi (3 KB per column written and read back, 12 GB per 2 M columns) the counts are
+// packed ONCE into the A-fragment the recurrence kernel wants -- rows (window, hi|lo), one k-step
+// of 32 slots = [features 0..I-1, constant 1 (bias row), zeros], fp16 hi/lo split of x * sx --
+// 1 KB per (work-group, t), and the recurrence issues 6 extra MFMAs per wave per step under the
+// LDS latency.  sx is chosen at load time so that (x*sx)(W_ih*swx) lands in the accumulator
+// scale S; inputs with |x| * sx beyond fp16 range raise `oor` and the engine falls back to the
+// exact fp32 projection kernel ON THE DEVICE (both paths are enqueued, the flag selects).
+__global__ __launch_bounds__(256) void k_pack_x(
+    const float *__restrict__ x,   // [B][T][I]
+    half8 *__restrict__ xfrag,     // [n_wg][T][64]
+    int B, int T, int I, int nq, int n_wg, float sx, int *__restrict__ oor)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_wg * T * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const size_t wt = idx >> 6;
+    const int t = (int)(wt % T);
+    const int wg = (int)(wt / T);
+    const int row = lane & 15, gq = lane >> 4;
+    const int g = row >> 2, split = row & 1;
+    int win;
+    bool live;
+    if (nq == 2) { win = wg * 8 + 2 * g + ((row >> 1) & 1); live = true; }
+    else { win = wg * 4 + g; live = ((row >> 1) & 1) == 0; }
+    live = live && (win < B);
+    half8 v;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = 8 * gq + i;
+        float val = 0.f;
+        if (live) {
+            if (f < I) val = x[((size_t)win * T + t) * I + f] * sx;
+            else if (f == I) val = sx;       // bias row of W_ih
+        }
+        bad |= !(fabsf(val) <= 60000.0f);
+        _Float16 hi, lo;
+        split_f16(val, hi, lo);
+        v[i] = split ? lo : hi;
+    }
+    xfrag[idx] = v;
+    if (bad) atomicOr(oor, 1);
 }
 
 }  // namespace mdk

@@ -116,6 +116,27 @@ def test_both_tile_sizes_agree_bitwise(gold):
     _check(outs[1], oracle.c_gru_forward(x, weight_set(gold, "x3")), what="8-window tiles")
 
 
+def test_fused_and_unfused_layer0_agree(gold):
+    x = synth.counts_windows(9, 400, seed=41)
+    ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
+    for fuse in (1, 0):
+        e = engine.GruEngine(weight_set(gold, "x3"))
+        e.set_option("fuse_l0", fuse)
+        _check(e.forward_host(x), ref, what=f"fuse_l0={fuse}")
+        e.close()
+
+
+def test_out_of_range_input_takes_exact_projection(gold, engines):
+    """Raw (un-normalised) counts overflow the fp16 packing of the fused layer-0 projection: the
+    engine must detect it on the device and fall back to the exact fp32 projection."""
+    x = synth.counts_windows(5, 300, seed=43) * np.float32(3000.0)
+    ref = oracle.c_gru_forward(x, weight_set(gold, "init"))
+    _check(engines("init").forward_host(x), ref, what="out-of-range input")
+    # and the engine keeps working on in-range input afterwards
+    x2 = synth.counts_windows(5, 300, seed=44)
+    _check(engines("init").forward_host(x2), oracle.c_gru_forward(x2, weight_set(gold, "init")), what="after")
+
+
 def test_empty_inputs(gold, engines):
     e = engines("init")
     assert e.forward_host(np.zeros((0, 10, 10), np.float32)).shape == (0, 10, 5)
