@@ -105,9 +105,17 @@ int mdk_gru_set_variant(mdk_gru *m, int variant);
 /* `normalise` attribute of GRUModel (gru.py:56,68): 1 softmax, 0 logits. */
 int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 
-/* Tuning knobs (no reference counterpart): "rec_windows_per_tile" = 0 (auto) | 4 | 8;
- * "ablate" = timing-only ablation mask of the recurrence kernel (results invalid unless 0). */
+/* Tuning knobs (no reference counterpart):
+ *   "rec_windows_per_tile" = 0 (auto) | 4 | 8      recurrence work-group granularity
+ *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
+ *   "overlap_gemm"         = 0 | 1                  run the layer>=1 projection GEMM concurrently with
+ *                                                   the recurrence that consumes it (default 0)
+ *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
+ *                             unless 0; 64 = per-phase cycle counters, see mdk_gru_debug_read) */
 int mdk_gru_set_option(mdk_gru *m, const char *key, int value);
+
+/* Debug: phase cycle counters of the last recurrence launch under option "ablate" = 64. */
+int mdk_gru_debug_read(mdk_gru *m, unsigned long long *dst, int n);
 
 /* hipEvent timing of every kernel of the following forwards (adds a stream sync per forward). */
 int mdk_gru_enable_timing(mdk_gru *m, int on);

@@ -83,7 +83,12 @@ struct mdk_gru {
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
-    int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
+    int *oor_flag = nullptr;    // device flags: [0] layer-0 input out of fp16 range, [1] overlap spin timeout
+    int opt_overlap = 0;        // overlap k_gi_gemm with the recurrence that consumes it (measured: no gain, off)
+    hipStream_t s2 = nullptr;   // helper stream of the overlapped GEMM
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    unsigned *ready = nullptr;  // [layer][tile][chunk] producer counters
+    size_t ready_cap = 0;
     std::vector<LayerDev> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace (grown on demand)
@@ -113,6 +118,10 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->s2) (void)hipStreamDestroy(m->s2);
+    if (m->ev_a) (void)hipEventDestroy(m->ev_a);
+    if (m->ev_b) (void)hipEventDestroy(m->ev_b);
+    free_dev(m->ready);
     delete m;
 }
 
@@ -165,7 +174,10 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->layers.resize(L);
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_b, hipEventDisableTiming) != hipSuccess)
         return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
 
     for (int l = 0; l < L; ++l) {
@@ -287,7 +299,8 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
             }
         }
     }
-    if (hipMalloc((void **)&m->oor_flag, sizeof(int)) != hipSuccess) return bail(fail(MDK_ERR_OOM, "hipMalloc failed"));
+    if (hipMalloc((void **)&m->oor_flag, 8192) != hipSuccess) return bail(fail(MDK_ERR_OOM, "hipMalloc failed"));
+    (void)hipMemset(m->oor_flag, 0, 8192);
     {
         std::vector<float> lw(weights[4 * L * D], weights[4 * L * D] + (size_t)C * D * H);
         std::vector<float> lb(weights[4 * L * D + 1], weights[4 * L * D + 1] + C);
@@ -295,9 +308,9 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         if ((rc = upload(&m->lin_b, lb))) return bail(rc);
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8 * 64 * 16));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 64 * 16));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 4 * 64 * 16));
     *out = m;
     return MDK_OK;
 }
@@ -328,9 +341,19 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_ablate = value;
     } else if (!strcmp(key, "fuse_l0")) {
         m->opt_fuse_l0 = value ? 1 : 0;
+    } else if (!strcmp(key, "overlap_gemm")) {
+        m->opt_overlap = value ? 1 : 0;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
+    return MDK_OK;
+}
+// debug: per-phase cycle counters written by the ablate=64 build of the recurrence kernel
+extern "C" int mdk_gru_debug_read(mdk_gru *m, unsigned long long *dst, int n) {
+    if (!m || !dst || n < 0 || n > 768) return fail(MDK_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, reinterpret_cast<char *>(m->oor_flag) + 64, (size_t)n * 8, hipMemcpyDeviceToHost));
     return MDK_OK;
 }
 extern "C" int mdk_gru_enable_timing(mdk_gru *m, int on) {
@@ -366,22 +389,24 @@ struct EvTimer {
     mdk_gru *m;
     hipStream_t s;
     size_t next = 0;
+    hipStream_t cur = nullptr;
     std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;  // slot id -> (start, stop)
-    int begin(int slot) {
+    int begin(int slot, hipStream_t on = (hipStream_t)-1) {
         if (!m->timing) return MDK_OK;
+        if (on != (hipStream_t)-1) cur = on; else cur = s;
         while (m->ev.size() < next + 2) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             m->ev.push_back(e);
         }
-        HIP_TRY(hipEventRecord(m->ev[next], s));
+        HIP_TRY(hipEventRecord(m->ev[next], cur));
         spans.push_back({slot, {next, next + 1}});
         next += 2;
         return MDK_OK;
     }
     int end() {
         if (!m->timing) return MDK_OK;
-        HIP_TRY(hipEventRecord(m->ev[spans.back().second.second], s));
+        HIP_TRY(hipEventRecord(m->ev[spans.back().second.second], cur));
         return MDK_OK;
     }
 };
@@ -440,13 +465,37 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if (m->opt_tile_windows == 8) nq = 2;
     const int n_wg = nq == 1 ? 2 * n_tiles : n_tiles;
     const dim3 rgrid(n_wg, D);
+    // GEMM / recurrence overlap: only while the recurrence leaves at least half of the CUs free for
+    // the producer (a spinning consumer never yields its CU)
+    const int chunk_steps = 128, n_chunks = (T + chunk_steps - 1) / chunk_steps;
+    const bool overlap = m->opt_overlap && L > 1 && n_wg * D <= 128 && abl == 0;
+    if (overlap) {
+        const size_t need = (size_t)L * n_tiles * n_chunks;
+        if (need > m->ready_cap) {
+            free_dev(m->ready); m->ready = nullptr; m->ready_cap = 0;
+            HIP_TRY(hipMalloc((void **)&m->ready, need * sizeof(unsigned)));
+            m->ready_cap = need;
+        }
+        HIP_TRY(hipMemsetAsync(m->ready, 0, need * sizeof(unsigned), s));
+        HIP_TRY(hipMemsetAsync(m->oor_flag + 1, 0, sizeof(int), s));
+    }
 
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
         const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr;
         const int *cond = fuse ? m->oor_flag : nullptr;
-        if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
+        const bool ovl = overlap && l > 0;
+        unsigned *ready = ovl ? m->ready + (size_t)l * n_tiles * n_chunks : nullptr;
+        hipStream_t gs = s;   // stream of this layer's input projection
+        if (ovl) {
+            // the producer starts when the previous layer is complete, on its own stream; the
+            // consumer (this layer's recurrence) is enqueued on `s` right behind the previous layer
+            HIP_TRY(hipEventRecord(m->ev_a, s));
+            HIP_TRY(hipStreamWaitEvent(m->s2, m->ev_a, 0));
+            gs = m->s2;
+        }
+        if ((rc = tm.begin(SLOT_GI0 + l, gs))) return rc;
         if (fuse) {
             const size_t need = (size_t)n_wg * T * 64;
             if (need > m->xfrag_cap) {
@@ -465,21 +514,23 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, in,
                                Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec, cond, 1);
         } else {
-            const dim3 grid((T + kGemmSteps - 1) / kGemmSteps, n_tiles);
+            const dim3 grid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
             if (D == 2)
-                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(512), (size_t)2 * 8 * 8 * 64 * sizeof(half8), s, in,
+                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(512), (size_t)2 * kGemmMT * 8 * 64 * sizeof(half8), gs, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec);
+                                   Ld.up_scale_rec, ready, n_chunks, chunk_steps / kGemmSteps);
             else
-                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(512), (size_t)2 * 8 * 4 * 64 * sizeof(half8), s, in,
+                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(512), (size_t)2 * kGemmMT * 4 * 64 * sizeof(half8), gs, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec);
+                                   Ld.up_scale_rec, ready, n_chunks, chunk_steps / kGemmSteps);
         }
         if ((rc = tm.end())) return rc;
+        if (ovl) HIP_TRY(hipEventRecord(m->ev_b, m->s2));
         if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
 #define MDK_REC_ARGS(XIN, CND, WANT)                                                               \
     m->gi, m->xfrag, Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,     \
-        reverse_mask, CND, WANT
+        reverse_mask, CND, WANT, ready, n_chunks, chunk_steps, kGemmSteps,                         \
+        reinterpret_cast<unsigned *>(m->oor_flag + 1)
 #define MDK_LAUNCH_REC(XIN, A, CND, WANT)                                                          \
     do {                                                                                           \
         if (nq == 1)                                                                               \
@@ -499,6 +550,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         case 16: MDK_LAUNCH_REC(XIN, 16, CND, WANT); break;                                        \
         case 7: MDK_LAUNCH_REC(XIN, 7, CND, WANT); break;                                          \
         case 31: MDK_LAUNCH_REC(XIN, 31, CND, WANT); break;                                        \
+        case 64: MDK_LAUNCH_REC(XIN, 64, m->oor_flag, 0); break;                                   \
         default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);                    \
     }
         if (fuse) {
@@ -511,6 +563,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
 #undef MDK_LAUNCH_REC
 #undef MDK_REC_ARGS
         if ((rc = tm.end())) return rc;
+        if (ovl) HIP_TRY(hipStreamWaitEvent(s, m->ev_b, 0));   // rejoin before anything reuses gi / act
         m->last.rec_launches++;
         in = outp;
     }
@@ -530,9 +583,20 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     return MDK_OK;
 }
 
+// after a synchronised forward: did a consumer give up waiting for the overlapped producer?
+static int check_device_flags(mdk_gru *m) {
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, m->oor_flag, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[1] != 0)
+        return fail(MDK_ERR_DEVICE, "recurrence kernel timed out waiting for the overlapped input projection "
+                                    "(set option overlap_gemm=0)");
+    return MDK_OK;
+}
+
 static int finish_timing(mdk_gru *m, EvTimer &tm, hipStream_t s) {
     if (!m->timing) return MDK_OK;
     HIP_TRY(hipStreamSynchronize(s));
+    if (int rc = check_device_flags(m)) return rc;
     for (auto &sp : tm.spans) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, m->ev[sp.second.first], m->ev[sp.second.second]));
@@ -607,6 +671,7 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
     HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     if (m->timing) HIP_TRY(hipEventRecord(e3, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if ((rc = check_device_flags(m))) return rc;
     if (m->timing) {
         HIP_TRY(hipEventElapsedTime(&m->last.h2d_ms, e0, e1));
         HIP_TRY(hipEventElapsedTime(&m->last.d2h_ms, e2, e3));

@@ -72,36 +72,46 @@ __global__ __launch_bounds__(768) void k_gi_small(
 }
 
 // ------------------------------------------------------------------------------------------
-// layers >= 1.  Work-group = 8 waves (2 per SIMD: the 4-wave version was instruction-issue
-// bound, matrix pipe 31 % busy), M-tile = one window tile x 16 time steps = 128 rows, read as ONE
-// contiguous run of 16 activation blocks.  MFMA row 4g + 2q + tt of row-tile mt is
+// layers >= 1.  Work-group = 8 waves (the 4-wave version was instruction-issue bound, matrix pipe
+// 31 % busy), M-tile = one window tile x 8 time steps = 64 rows, read as ONE contiguous run of 8
+// activation blocks; 64 KB of LDS and <= 128 VGPRs so that TWO work-groups share a CU and one
+// loads / stores while the other computes (a 128-row tile with one work-group per CU serialised
+// load, compute and the 384 KB store tail: 2.6 ms -> measured below).  MFMA row 4g + 2q + tt of row-tile mt is
 // (window 2g+q, t0 + 2*mt + tt), so accumulator register r = 2q + tt of lane g*16+c is exactly
 // element `lane` of gi block t0+2mt+tt, sub-block (w8, q, gate): every accumulator register is
 // stored by the wave as one contiguous 256-byte run.  The x tile is converted once to fp16
-// hi/lo A-fragments in LDS (128 KB at K = 256); W_ih B-fragments stream from L2, pre-packed so
+// hi/lo A-fragments in LDS (64 KB at K = 256); W_ih B-fragments stream from L2, pre-packed so
 // that each lane issues one 16-byte load per fragment.  One pass per output direction: wave w8
 // owns hidden units 16*w8 .. +15 of all three gates (24 accumulator tiles).
-constexpr int kGemmSteps = 16;
+constexpr int kGemmSteps = 8;                  // time steps per work-group: M-tile = 8 windows x 8 steps
+constexpr int kGemmMT = kGemmSteps / 2;        // 16-row MFMA tiles per M-tile
 
 template <int KSTEPS>   // K = 32 * KSTEPS = D_in * 128
-__global__ __launch_bounds__(512, 2) void k_gi_gemm(
+__global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
     const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
     const float *__restrict__ bias,    // [D][384]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
-    const float *__restrict__ out_scale_p)
+    const float *__restrict__ out_scale_p,
+    unsigned *__restrict__ ready, int n_chunks, int strips_per_chunk)
 {
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half8 *xs = reinterpret_cast<half8 *>(smem);   // [split 2][mt 8][KSTEPS][64 lanes]
+    half8 *xs = reinterpret_cast<half8 *>(smem);   // [split 2][mt kGemmMT][KSTEPS][64 lanes]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.y;
-    const int t0 = blockIdx.x * kGemmSteps;
+    // 1-D grid, tile fastest.  With `ready` (GEMM overlapped with the consuming recurrence, see
+    // rec_mfma.hpp) strips are issued from both ends of the window inwards, so that the forward
+    // and the backward recurrence both find their first chunks early.
+    const int tile = blockIdx.x % n_tiles;
+    const int sidx = blockIdx.x / n_tiles;
+    const int n_strips = (T + kGemmSteps - 1) / kGemmSteps;
+    const int strip = (ready == nullptr) ? sidx : ((sidx & 1) ? (n_strips - 1 - (sidx >> 1)) : (sidx >> 1));
+    const int t0 = strip * kGemmSteps;
 
     // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)
     {
@@ -131,16 +141,16 @@ __global__ __launch_bounds__(512, 2) void k_gi_gemm(
             const int row = 4 * g + 2 * q + (tau & 1), mt = tau >> 1;
             const int k8 = chunk * 2 + half, ks = k8 >> 2;
             const int slot = (k8 & 3) * 16 + row;      // A-fragment lane that consumes it
-            xs[((0 * 8 + mt) * KSTEPS + ks) * 64 + slot] = hi;
-            xs[((1 * 8 + mt) * KSTEPS + ks) * 64 + slot] = lo;
+            xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = hi;
+            xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = lo;
         }
     }
     __syncthreads();
 
     for (int d = 0; d < D; ++d) {
-        floatx4 acc[8][3];
+        floatx4 acc[kGemmMT][3];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < kGemmMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
@@ -154,9 +164,9 @@ __global__ __launch_bounds__(512, 2) void k_gi_gemm(
                 bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
             }
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                const half8 ah = xs[((0 * 8 + mt) * KSTEPS + ks) * 64 + lane];
-                const half8 al = xs[((1 * 8 + mt) * KSTEPS + ks) * 64 + lane];
+            for (int mt = 0; mt < kGemmMT; ++mt) {
+                const half8 ah = xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
+                const half8 al = xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_gi_gemm(
         for (int nt = 0; nt < 3; ++nt) bv[nt] = bias[(size_t)d * kG + nt * kH + 16 * w8 + (lane & 15)] * os;
         float *gblk = gi + gi_block(d, n_tiles, tile, T, t0);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < kGemmMT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = r >> 1, tt = r & 1;
@@ -185,6 +195,18 @@ __global__ __launch_bounds__(512, 2) void k_gi_gemm(
                     for (int nt = 0; nt < 3; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
                 }
             }
+        }
+    }
+    if (ready != nullptr) {
+        // publish: every wave drains its stores, one lane releases at agent scope and bumps the
+        // (tile, chunk) counter the recurrence kernel polls (cdna_hip_programming.md G16)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&ready[(size_t)tile * n_chunks + strip / strips_per_chunk], 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

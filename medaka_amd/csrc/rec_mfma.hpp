@@ -52,7 +52,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ b_hn,    // [D][128]  (unscaled)
     float *__restrict__ out,           // act_t (layout.hpp)
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask,
-    const int *__restrict__ cond, int want)
+    const int *__restrict__ cond, int want,
+    const unsigned *__restrict__ ready, int n_chunks, int chunk_steps, int gemm_steps,
+    unsigned *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
@@ -124,6 +126,33 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     // PF steps.)
     float gq[PF][3 * NQ];
     half8 xq[PF];
+    // Overlapped mode (`ready` != null): gi of this layer is being produced by k_gi_gemm on another
+    // stream while this kernel runs; before the ring first touches a chunk of `chunk_steps` time
+    // steps the wave polls the (tile, chunk) counter (relaxed, agent scope), then takes ONE
+    // agent-scope acquire.  Spins are bounded: on timeout `err` is raised and the kernel runs on.
+    auto acquire_chunk = [&](int t_load) {
+        const int ch = t_load / chunk_steps;
+        const int last_t = min(T, (ch + 1) * chunk_steps);
+        const unsigned expected = (unsigned)((last_t - ch * chunk_steps + gemm_steps - 1) / gemm_steps);
+        const unsigned *f = ready + (size_t)tile * n_chunks + ch;
+        unsigned spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+            __builtin_amdgcn_s_sleep(64);
+            // ~0.5 s in total; once any wave has given up everybody stops waiting
+            if (++spins > (1u << 18) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) atomicOr(err, 1u);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    auto maybe_acquire = [&](int sl) {   // sl = step whose gi is about to be fetched
+        if (ready != nullptr && sl < T) {
+            const int tl = reverse ? (T - 1 - sl) : sl;
+            const bool first_of_chunk = reverse ? ((tl + 1) % chunk_steps == 0) : (tl % chunk_steps == 0);
+            if (sl == 0 || first_of_chunk) acquire_chunk(tl);
+        }
+    };
     auto refill = [&](int p, bool advance) {
         if constexpr (XIN) {
             if constexpr (!(ABL & 8)) xq[p] = *xp;
@@ -142,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     for (int p = 0; p < PF; ++p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) xq[p][i] = (_Float16)0.f;
+        maybe_acquire(p);
         refill(p, p + 1 < T);
     }
 #pragma unroll
@@ -172,6 +202,29 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     asm volatile("" ::"v"(bhn));
     __syncthreads();
 
+    floatx4 xar = floatx4{0.f, 0.f, 0.f, 0.f}, xaz = xar, xgn = xar;
+    if constexpr (XIN && !(ABL & 1)) {
+        xar = mfma16(xq[0], wx[0][0], xar);
+        xaz = mfma16(xq[0], wx[1][0], xaz);
+        xgn = mfma16(xq[0], wx[2][0], xgn);
+        xar = mfma16(xq[0], wx[0][1], xar);
+        xaz = mfma16(xq[0], wx[1][1], xaz);
+        xgn = mfma16(xq[0], wx[2][1], xgn);
+    }
+    // ABL & 64: per-phase cycle accounting with s_memtime (perturbs the schedule; debug only)
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int ph) {
+        if constexpr (ABL & 64) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tph[ph] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (ABL & 64) tprev = __builtin_amdgcn_s_memtime();
+
     for (int step0 = 0; step0 < T; step0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -179,23 +232,16 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             if (step < T) {   // wave-uniform
                 const int cur = (step & 1) * kHBufBytes;
                 const int nxt = kHBufBytes - cur;
+                stamp(0);   // refill issue + loop overhead
 
                 half8 a[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
 
+                if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }   // LDS read latency
                 floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
-                if constexpr (XIN && !(ABL & 1)) {
-                    // layer-0 input projection: independent of h, issued while the LDS reads of h
-                    // are in flight; r and z continue into the same accumulators
-                    ar = mfma16(xq[p], wx[0][0], ar);
-                    az = mfma16(xq[p], wx[1][0], az);
-                    gin = mfma16(xq[p], wx[2][0], gin);
-                    ar = mfma16(xq[p], wx[0][1], ar);
-                    az = mfma16(xq[p], wx[1][1], az);
-                    gin = mfma16(xq[p], wx[2][1], gin);
-                }
+                if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
                 if constexpr (ABL & 1) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
@@ -210,38 +256,59 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         ar = mfma16(a[ks], wf[ks][0][1], ar);
                         az = mfma16(a[ks], wf[ks][1][1], az);
                     }
+                }
+                // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
+                // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
+                // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
+                // after the last MFMA.
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 1)) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
                         anh = mfma16(a[ks], wf[ks][2][0], anh);
                         anl = mfma16(a[ks], wf[ks][2][1], anl);
                     }
                 }
+                float rr[NQ], zz[NQ], gnv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float gr, gz;
+                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = gin[2 * q] + gin[2 * q + 1]; }
+                    else { gr = gq[p][q * 3]; gz = gq[p][q * 3 + 1]; gnv[q] = gq[p][q * 3 + 2]; }
+                    const float tr = XIN ? (ar[2 * q] + ar[2 * q + 1]) : ((gr + ar[2 * q]) + ar[2 * q + 1]);
+                    const float tz = XIN ? (az[2 * q] + az[2 * q + 1]) : ((gz + az[2 * q]) + az[2 * q + 1]);
+                    rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                    zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+                }
+                if constexpr (!(ABL & 1)) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(2);   // MFMA issue (+ sigmoids)
                 float hn[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    float gr, gz, gn;
-                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gn = gin[2 * q] + gin[2 * q + 1]; }
-                    else { gr = gq[p][q * 3]; gz = gq[p][q * 3 + 1]; gn = gq[p][q * 3 + 2]; }
                     if constexpr (ABL & 2) {
                         const float h = ((ar[2 * q] + az[2 * q + 1]) + (anh[2 * q] + anl[2 * q + 1])) * 1e-6f +
-                                        (gr + gz + gn) * 1e-9f;
+                                        (rr[q] + zz[q] + gnv[q]) * 1e-9f;
                         hprev[q] = h; hn[q] = h;
                         if constexpr (!(ABL & 16)) op[q][0] = h;
                         continue;
                     }
-                    const float tr = XIN ? (ar[2 * q] + ar[2 * q + 1]) : ((gr + ar[2 * q]) + ar[2 * q + 1]);
-                    const float tz = XIN ? (az[2 * q] + az[2 * q + 1]) : ((gz + az[2 * q]) + az[2 * q + 1]);
-                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
-                    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
                     const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                    const float an = __builtin_fmaf(r, tn, gn);
+                    const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
                     const float e = __builtin_amdgcn_exp2f(an * c_tanh);
                     const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                    const float h = __builtin_fmaf(z, hprev[q] - n, n);
+                    const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
                     hprev[q] = h;
                     hn[q] = h;
                     if constexpr (!(ABL & 16)) op[q][0] = h;
                 }
+                if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     _Float16 hi, lo;
@@ -250,11 +317,35 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
                     op[q] += ostride;
                 }
+                if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(4); }   // split + LDS write
+                if constexpr (XIN && !(ABL & 1)) {
+                    // layer-0 input projection of the NEXT step: independent of h, so it is
+                    // issued here and runs on the matrix pipe while this wave sits in the LDS
+                    // write -> barrier -> LDS read latency chain
+                    const half8 xn = xq[(p + 1) % PF];
+                    const floatx4 zero = floatx4{0.f, 0.f, 0.f, 0.f};
+                    xar = mfma16(xn, wx[0][0], zero);
+                    xaz = mfma16(xn, wx[1][0], zero);
+                    xgn = mfma16(xn, wx[2][0], zero);
+                    xar = mfma16(xn, wx[0][1], xar);
+                    xaz = mfma16(xn, wx[1][1], xaz);
+                    xgn = mfma16(xn, wx[2][1], xgn);
+                }
                 if constexpr (ABL & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();
+                stamp(5);   // barrier wait
             }
             // refill ring slot p for step + PF: unconditional and in ring order on every path
+            maybe_acquire(step + PF);
             refill(p, (step + PF + 1) < T);
+        }
+    }
+    if constexpr (ABL & 64) {
+        if (lane == 0 && blockIdx.x < 4 && cond != nullptr) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<int *>(cond) + 16) +
+                                      ((size_t)(blockIdx.y * 4 + blockIdx.x) * 8 + w8) * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dbg[i] = tph[i];
         }
     }
 }

@@ -39,6 +39,7 @@ ABI = {
     "mdk_gru_set_variant": (_i, [_vp, _i]),
     "mdk_gru_set_normalise": (_i, [_vp, _i]),
     "mdk_gru_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
+    "mdk_gru_debug_read": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_device": (_i, [_vp]),
