@@ -108,8 +108,6 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 /* Tuning knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8      recurrence work-group granularity
  *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
- *   "overlap_gemm"         = 0 | 1                  run the layer>=1 projection GEMM concurrently with
- *                                                   the recurrence that consumes it (default 0)
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
  *                             unless 0; 64 = per-phase cycle counters, see mdk_gru_debug_read) */
 int mdk_gru_set_option(mdk_gru *m, const char *key, int value);

@@ -23,7 +23,7 @@
 using namespace mdk;
 
 #ifndef MDK_PF
-#define MDK_PF 4
+#define MDK_PF 5   // gi / x prefetch ring depth (effective look-ahead PF-1 steps)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -83,12 +83,7 @@ struct mdk_gru {
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
-    int *oor_flag = nullptr;    // device flags: [0] layer-0 input out of fp16 range, [1] overlap spin timeout
-    int opt_overlap = 0;        // overlap k_gi_gemm with the recurrence that consumes it (measured: no gain, off)
-    hipStream_t s2 = nullptr;   // helper stream of the overlapped GEMM
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    unsigned *ready = nullptr;  // [layer][tile][chunk] producer counters
-    size_t ready_cap = 0;
+    int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
     std::vector<LayerDev> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace (grown on demand)
@@ -118,10 +113,6 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
-    if (m->s2) (void)hipStreamDestroy(m->s2);
-    if (m->ev_a) (void)hipEventDestroy(m->ev_a);
-    if (m->ev_b) (void)hipEventDestroy(m->ev_b);
-    free_dev(m->ready);
     delete m;
 }
 
@@ -174,10 +165,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->layers.resize(L);
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_b, hipEventDisableTiming) != hipSuccess)
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
 
     for (int l = 0; l < L; ++l) {
@@ -341,8 +329,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_ablate = value;
     } else if (!strcmp(key, "fuse_l0")) {
         m->opt_fuse_l0 = value ? 1 : 0;
-    } else if (!strcmp(key, "overlap_gemm")) {
-        m->opt_overlap = value ? 1 : 0;
+
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -465,36 +452,12 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if (m->opt_tile_windows == 8) nq = 2;
     const int n_wg = nq == 1 ? 2 * n_tiles : n_tiles;
     const dim3 rgrid(n_wg, D);
-    // GEMM / recurrence overlap: only while the recurrence leaves at least half of the CUs free for
-    // the producer (a spinning consumer never yields its CU)
-    const int chunk_steps = 128, n_chunks = (T + chunk_steps - 1) / chunk_steps;
-    const bool overlap = m->opt_overlap && L > 1 && n_wg * D <= 128 && abl == 0;
-    if (overlap) {
-        const size_t need = (size_t)L * n_tiles * n_chunks;
-        if (need > m->ready_cap) {
-            free_dev(m->ready); m->ready = nullptr; m->ready_cap = 0;
-            HIP_TRY(hipMalloc((void **)&m->ready, need * sizeof(unsigned)));
-            m->ready_cap = need;
-        }
-        HIP_TRY(hipMemsetAsync(m->ready, 0, need * sizeof(unsigned), s));
-        HIP_TRY(hipMemsetAsync(m->oor_flag + 1, 0, sizeof(int), s));
-    }
-
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
         const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr;
         const int *cond = fuse ? m->oor_flag : nullptr;
-        const bool ovl = overlap && l > 0;
-        unsigned *ready = ovl ? m->ready + (size_t)l * n_tiles * n_chunks : nullptr;
-        hipStream_t gs = s;   // stream of this layer's input projection
-        if (ovl) {
-            // the producer starts when the previous layer is complete, on its own stream; the
-            // consumer (this layer's recurrence) is enqueued on `s` right behind the previous layer
-            HIP_TRY(hipEventRecord(m->ev_a, s));
-            HIP_TRY(hipStreamWaitEvent(m->s2, m->ev_a, 0));
-            gs = m->s2;
-        }
+        hipStream_t gs = s;
         if ((rc = tm.begin(SLOT_GI0 + l, gs))) return rc;
         if (fuse) {
             const size_t need = (size_t)n_wg * T * 64;
@@ -518,19 +481,17 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             if (D == 2)
                 hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(512), (size_t)2 * kGemmMT * 8 * 64 * sizeof(half8), gs, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec, ready, n_chunks, chunk_steps / kGemmSteps);
+                                   Ld.up_scale_rec);
             else
                 hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(512), (size_t)2 * kGemmMT * 4 * 64 * sizeof(half8), gs, in,
                                    Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec, ready, n_chunks, chunk_steps / kGemmSteps);
+                                   Ld.up_scale_rec);
         }
         if ((rc = tm.end())) return rc;
-        if (ovl) HIP_TRY(hipEventRecord(m->ev_b, m->s2));
         if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
 #define MDK_REC_ARGS(XIN, CND, WANT)                                                               \
     m->gi, m->xfrag, Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,     \
-        reverse_mask, CND, WANT, ready, n_chunks, chunk_steps, kGemmSteps,                         \
-        reinterpret_cast<unsigned *>(m->oor_flag + 1)
+        reverse_mask, CND, WANT
 #define MDK_LAUNCH_REC(XIN, A, CND, WANT)                                                          \
     do {                                                                                           \
         if (nq == 1)                                                                               \
@@ -563,7 +524,6 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
 #undef MDK_LAUNCH_REC
 #undef MDK_REC_ARGS
         if ((rc = tm.end())) return rc;
-        if (ovl) HIP_TRY(hipStreamWaitEvent(s, m->ev_b, 0));   // rejoin before anything reuses gi / act
         m->last.rec_launches++;
         in = outp;
     }
@@ -583,20 +543,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     return MDK_OK;
 }
 
-// after a synchronised forward: did a consumer give up waiting for the overlapped producer?
-static int check_device_flags(mdk_gru *m) {
-    int flags[2] = {0, 0};
-    HIP_TRY(hipMemcpy(flags, m->oor_flag, sizeof(flags), hipMemcpyDeviceToHost));
-    if (flags[1] != 0)
-        return fail(MDK_ERR_DEVICE, "recurrence kernel timed out waiting for the overlapped input projection "
-                                    "(set option overlap_gemm=0)");
-    return MDK_OK;
-}
-
 static int finish_timing(mdk_gru *m, EvTimer &tm, hipStream_t s) {
     if (!m->timing) return MDK_OK;
     HIP_TRY(hipStreamSynchronize(s));
-    if (int rc = check_device_flags(m)) return rc;
     for (auto &sp : tm.spans) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, m->ev[sp.second.first], m->ev[sp.second.second]));
@@ -671,7 +620,6 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
     HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     if (m->timing) HIP_TRY(hipEventRecord(e3, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    if ((rc = check_device_flags(m))) return rc;
     if (m->timing) {
         HIP_TRY(hipEventElapsedTime(&m->last.h2d_ms, e0, e1));
         HIP_TRY(hipEventElapsedTime(&m->last.d2h_ms, e2, e3));

@@ -93,8 +93,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ bias,    // [D][384]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
-    const float *__restrict__ out_scale_p,
-    unsigned *__restrict__ ready, int n_chunks, int strips_per_chunk)
+    const float *__restrict__ out_scale_p)
 {
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
@@ -104,13 +103,9 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 1-D grid, tile fastest.  With `ready` (GEMM overlapped with the consuming recurrence, see
-    // rec_mfma.hpp) strips are issued from both ends of the window inwards, so that the forward
-    // and the backward recurrence both find their first chunks early.
+    // 1-D grid, tile fastest
     const int tile = blockIdx.x % n_tiles;
-    const int sidx = blockIdx.x / n_tiles;
-    const int n_strips = (T + kGemmSteps - 1) / kGemmSteps;
-    const int strip = (ready == nullptr) ? sidx : ((sidx & 1) ? (n_strips - 1 - (sidx >> 1)) : (sidx >> 1));
+    const int strip = blockIdx.x / n_tiles;
     const int t0 = strip * kGemmSteps;
 
     // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)
@@ -195,18 +190,6 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
                     for (int nt = 0; nt < 3; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
                 }
             }
-        }
-    }
-    if (ready != nullptr) {
-        // publish: every wave drains its stores, one lane releases at agent scope and bumps the
-        // (tile, chunk) counter the recurrence kernel polls (cdna_hip_programming.md G16)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&ready[(size_t)tile * n_chunks + strip / strips_per_chunk], 1u,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -52,9 +52,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ b_hn,    // [D][128]  (unscaled)
     float *__restrict__ out,           // act_t (layout.hpp)
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask,
-    const int *__restrict__ cond, int want,
-    const unsigned *__restrict__ ready, int n_chunks, int chunk_steps, int gemm_steps,
-    unsigned *__restrict__ err)
+    const int *__restrict__ cond, int want)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
@@ -126,33 +124,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     // PF steps.)
     float gq[PF][3 * NQ];
     half8 xq[PF];
-    // Overlapped mode (`ready` != null): gi of this layer is being produced by k_gi_gemm on another
-    // stream while this kernel runs; before the ring first touches a chunk of `chunk_steps` time
-    // steps the wave polls the (tile, chunk) counter (relaxed, agent scope), then takes ONE
-    // agent-scope acquire.  Spins are bounded: on timeout `err` is raised and the kernel runs on.
-    auto acquire_chunk = [&](int t_load) {
-        const int ch = t_load / chunk_steps;
-        const int last_t = min(T, (ch + 1) * chunk_steps);
-        const unsigned expected = (unsigned)((last_t - ch * chunk_steps + gemm_steps - 1) / gemm_steps);
-        const unsigned *f = ready + (size_t)tile * n_chunks + ch;
-        unsigned spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-            __builtin_amdgcn_s_sleep(64);
-            // ~0.5 s in total; once any wave has given up everybody stops waiting
-            if (++spins > (1u << 18) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                if (lane == 0) atomicOr(err, 1u);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    };
-    auto maybe_acquire = [&](int sl) {   // sl = step whose gi is about to be fetched
-        if (ready != nullptr && sl < T) {
-            const int tl = reverse ? (T - 1 - sl) : sl;
-            const bool first_of_chunk = reverse ? ((tl + 1) % chunk_steps == 0) : (tl % chunk_steps == 0);
-            if (sl == 0 || first_of_chunk) acquire_chunk(tl);
-        }
-    };
     auto refill = [&](int p, bool advance) {
         if constexpr (XIN) {
             if constexpr (!(ABL & 8)) xq[p] = *xp;
@@ -171,11 +142,17 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     for (int p = 0; p < PF; ++p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) xq[p][i] = (_Float16)0.f;
-        maybe_acquire(p);
+#pragma unroll
+        for (int i = 0; i < 3 * NQ; ++i) gq[p][i] = 0.f;
+    }
+    // slots 0..PF-2 hold steps 0..PF-2; slot PF-1 is filled during step 0 (for step PF-1): a slot
+    // is always refilled one step after it was consumed, from inside the MFMA phase
+#pragma unroll
+    for (int p = 0; p + 1 < PF; ++p) {
         refill(p, p + 1 < T);
     }
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
+    for (int p = 0; p + 1 < PF; ++p) {
         if constexpr (XIN) asm volatile("" ::"v"(xq[p]));
         else {
 #pragma unroll
@@ -229,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int step = step0 + p;
-            if (step < T) {   // wave-uniform
+            {   // steps >= T (T not a multiple of PF) run too, with their stores masked
                 const int cur = (step & 1) * kHBufBytes;
                 const int nxt = kHBufBytes - cur;
                 stamp(0);   // refill issue + loop overhead
@@ -257,6 +234,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         az = mfma16(a[ks], wf[ks][1][1], az);
                     }
                 }
+                // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
+                // vector-memory issue hides under the MFMAs; unconditional, in ring order
+                refill((p + PF - 1) % PF, (step + PF) < T);
                 // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
                 // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
                 // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
@@ -296,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float h = ((ar[2 * q] + az[2 * q + 1]) + (anh[2 * q] + anl[2 * q + 1])) * 1e-6f +
                                         (rr[q] + zz[q] + gnv[q]) * 1e-9f;
                         hprev[q] = h; hn[q] = h;
-                        if constexpr (!(ABL & 16)) op[q][0] = h;
+                        if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
                         continue;
                     }
                     const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
@@ -306,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
                     hprev[q] = h;
                     hn[q] = h;
-                    if constexpr (!(ABL & 16)) op[q][0] = h;
+                    if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
                 }
                 if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain
 #pragma unroll
@@ -335,9 +315,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 lds_barrier();
                 stamp(5);   // barrier wait
             }
-            // refill ring slot p for step + PF: unconditional and in ring order on every path
-            maybe_acquire(step + PF);
-            refill(p, (step + PF + 1) < T);
         }
     }
     if constexpr (ABL & 64) {

@@ -137,20 +137,6 @@ def test_out_of_range_input_takes_exact_projection(gold, engines):
     _check(engines("init").forward_host(x2), oracle.c_gru_forward(x2, weight_set(gold, "init")), what="after")
 
 
-def test_overlapped_and_sequential_projection_agree(gold):
-    """The layer-1 projection GEMM runs concurrently with the recurrence that consumes it
-    (producer/consumer flags); results must be bit-identical to the sequential schedule."""
-    x = synth.counts_windows(11, 1500, seed=51)
-    outs = []
-    for ovl in (1, 0):
-        e = engine.GruEngine(weight_set(gold, "x3"))
-        e.set_option("overlap_gemm", ovl)
-        outs.append(e.forward_host(x))
-        e.close()
-    assert np.array_equal(outs[0], outs[1])
-    _check(outs[0], oracle.c_gru_forward(x, weight_set(gold, "x3")), what="overlapped")
-
-
 def test_empty_inputs(gold, engines):
     e = engines("init")
     assert e.forward_host(np.zeros((0, 10, 10), np.float32)).shape == (0, 10, 5)
