@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=8, help="windows in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
-    ap.add_argument("--tile", type=int, default=0, help="recurrence windows per tile (0 auto, 4, 8)")
+    ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
     return ap.parse_args()
 

@@ -295,10 +295,8 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         if ((rc = upload(&m->lin_w, lw))) return bail(rc);
         if ((rc = upload(&m->lin_b, lb))) return bail(rc);
     }
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 4 * 64 * 16));
     *out = m;
     return MDK_OK;
 }
@@ -323,7 +321,8 @@ extern "C" int mdk_gru_set_normalise(mdk_gru *m, int normalise) {
 extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     if (!m || !key) return fail(MDK_ERR_ARG, "null argument");
     if (!strcmp(key, "rec_windows_per_tile")) {
-        if (value != 0 && value != 4 && value != 8) return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4 or 8");
+        if (value != 0 && value != 4 && value != 8 && value != 16)
+            return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
         m->opt_tile_windows = value;
     } else if (!strcmp(key, "ablate")) {
         m->opt_ablate = value;
@@ -446,19 +445,25 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // "ablate" option / MDK_ABLATE=<mask>: timing-only ablations (wrong results)
     static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
     const int abl = m->opt_ablate ? m->opt_ablate : env_abl;
-    // half-tile (4-window) work-groups while they fit the chip in one round, else whole tiles
-    int nq = (2 * n_tiles) * D <= 256 ? 1 : 2;
+    // work-group granularity of the recurrence: 4 windows while that fits the chip in one round of
+    // work-groups (latency-bound regime), else 8, else (half-precision mode only) 16
+    const bool hp = (m->precision == MDK_PREC_FP16);
+    const int n_win = n_tiles * kTileWin;
+    int nq = 1;
+    while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > 256) nq *= 2;
     if (m->opt_tile_windows == 4) nq = 1;
     if (m->opt_tile_windows == 8) nq = 2;
-    const int n_wg = nq == 1 ? 2 * n_tiles : n_tiles;
+    if (m->opt_tile_windows == 16 && hp) nq = 4;
+    const int n_wg = (n_win + 4 * nq - 1) / (4 * nq);
     const dim3 rgrid(n_wg, D);
+
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
-        const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr;
+        const bool ablated = (abl != 0 && !hp && nq <= 2);
+        const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr && !ablated;
         const int *cond = fuse ? m->oor_flag : nullptr;
-        hipStream_t gs = s;
-        if ((rc = tm.begin(SLOT_GI0 + l, gs))) return rc;
+        if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
         if (fuse) {
             const size_t need = (size_t)n_wg * T * 64;
             if (need > m->xfrag_cap) {
@@ -468,7 +473,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             }
             HIP_TRY(hipMemsetAsync(m->oor_flag, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, in, m->xfrag, nb, T,
-                               Ld.K, nq, n_wg, Ld.x_scale, m->oor_flag);
+                               Ld.K, nq, hp ? 1 : 0, n_wg, Ld.x_scale, m->oor_flag);
         }
         if (l == 0) {
             // unfused layer-0 projection: the only path without fusion, the on-device fallback
@@ -478,51 +483,51 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                                Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec, cond, 1);
         } else {
             const dim3 grid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
-            if (D == 2)
-                hipLaunchKernelGGL(k_gi_gemm<8>, grid, dim3(512), (size_t)2 * kGemmMT * 8 * 64 * sizeof(half8), gs, in,
-                                   Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec);
-            else
-                hipLaunchKernelGGL(k_gi_gemm<4>, grid, dim3(512), (size_t)2 * kGemmMT * 4 * 64 * sizeof(half8), gs, in,
-                                   Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi,
-                                   Ld.up_scale_rec);
+#define MDK_GEMM(KS, HPF)                                                                          \
+    hipLaunchKernelGGL((k_gi_gemm<KS, HPF>), grid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
+                       in, Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi, Ld.up_scale_rec)
+            if (D == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
+            else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
+#undef MDK_GEMM
         }
         if ((rc = tm.end())) return rc;
         if ((rc = tm.begin(SLOT_REC0 + l))) return rc;
-#define MDK_REC_ARGS(XIN, CND, WANT)                                                               \
-    m->gi, m->xfrag, Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,     \
-        reverse_mask, CND, WANT
-#define MDK_LAUNCH_REC(XIN, A, CND, WANT)                                                          \
-    do {                                                                                           \
-        if (nq == 1)                                                                               \
-            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 1, XIN, A>), rgrid, dim3(512), 0, s,            \
-                               MDK_REC_ARGS(XIN, CND, WANT));                                      \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_rec_mfma<MDK_PF, 2, XIN, A>), rgrid, dim3(512), 0, s,            \
-                               MDK_REC_ARGS(XIN, CND, WANT));                                      \
-    } while (0)
-#define MDK_LAUNCH_REC_ABL(XIN, CND, WANT)                                                         \
-    switch (abl) {                                                                                 \
-        case 0: MDK_LAUNCH_REC(XIN, 0, CND, WANT); break;                                          \
-        case 1: MDK_LAUNCH_REC(XIN, 1, CND, WANT); break;                                          \
-        case 2: MDK_LAUNCH_REC(XIN, 2, CND, WANT); break;                                          \
-        case 4: MDK_LAUNCH_REC(XIN, 4, CND, WANT); break;                                          \
-        case 8: MDK_LAUNCH_REC(XIN, 8, CND, WANT); break;                                          \
-        case 16: MDK_LAUNCH_REC(XIN, 16, CND, WANT); break;                                        \
-        case 7: MDK_LAUNCH_REC(XIN, 7, CND, WANT); break;                                          \
-        case 31: MDK_LAUNCH_REC(XIN, 31, CND, WANT); break;                                        \
-        case 64: MDK_LAUNCH_REC(XIN, 64, m->oor_flag, 0); break;                                   \
-        default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);                    \
-    }
-        if (fuse) {
-            MDK_LAUNCH_REC_ABL(true, cond, 0);    // fused: runs unless the range flag is up
-            MDK_LAUNCH_REC(false, 0, cond, 1);    // fallback on the flag
+#define MDK_LAUNCH_REC(NQV, XIN, HPF, A, CND, WANT)                                                \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, A>), rgrid, dim3(512), 0, s, m->gi, m->xfrag, \
+                       Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
+                       reverse_mask, CND, WANT)
+        // production instantiations
+        auto launch = [&](bool xin, const int *cnd, int want) {
+            if (hp) {
+                if (nq == 1) { if (xin) MDK_LAUNCH_REC(1, true, true, 0, cnd, want); else MDK_LAUNCH_REC(1, false, true, 0, cnd, want); }
+                else if (nq == 2) { if (xin) MDK_LAUNCH_REC(2, true, true, 0, cnd, want); else MDK_LAUNCH_REC(2, false, true, 0, cnd, want); }
+                else { if (xin) MDK_LAUNCH_REC(4, true, true, 0, cnd, want); else MDK_LAUNCH_REC(4, false, true, 0, cnd, want); }
+            } else {
+                if (nq == 1) { if (xin) MDK_LAUNCH_REC(1, true, false, 0, cnd, want); else MDK_LAUNCH_REC(1, false, false, 0, cnd, want); }
+                else { if (xin) MDK_LAUNCH_REC(2, true, false, 0, cnd, want); else MDK_LAUNCH_REC(2, false, false, 0, cnd, want); }
+            }
+        };
+        if (ablated) {
+            // timing-only ablations: fp32-parity mode, unfused input, 4- or 8-window work-groups
+#define MDK_ABL_CASE(A)                                                                            \
+    case A:                                                                                        \
+        if (nq == 1) MDK_LAUNCH_REC(1, false, false, A, (A & 64) ? m->oor_flag : (const int *)nullptr, 0); \
+        else MDK_LAUNCH_REC(2, false, false, A, (A & 64) ? m->oor_flag : (const int *)nullptr, 0);  \
+        break;
+            if (abl & 64) HIP_TRY(hipMemsetAsync(m->oor_flag, 0, sizeof(int), s));
+            switch (abl) {
+                MDK_ABL_CASE(1) MDK_ABL_CASE(2) MDK_ABL_CASE(4) MDK_ABL_CASE(8) MDK_ABL_CASE(16)
+                MDK_ABL_CASE(7) MDK_ABL_CASE(31) MDK_ABL_CASE(64)
+                default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
+            }
+#undef MDK_ABL_CASE
+        } else if (fuse) {
+            launch(true, cond, 0);     // fused: runs unless the range flag is up
+            launch(false, cond, 1);    // fallback on the flag
         } else {
-            MDK_LAUNCH_REC_ABL(false, nullptr, 0);
+            launch(false, nullptr, 0);
         }
-#undef MDK_LAUNCH_REC_ABL
 #undef MDK_LAUNCH_REC
-#undef MDK_REC_ARGS
         if ((rc = tm.end())) return rc;
         m->last.rec_launches++;
         in = outp;

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(768) void k_gi_small(
 constexpr int kGemmSteps = 8;                  // time steps per work-group: M-tile = 8 windows x 8 steps
 constexpr int kGemmMT = kGemmSteps / 2;        // 16-row MFMA tiles per M-tile
 
-template <int KSTEPS>   // K = 32 * KSTEPS = D_in * 128
+// HP: half-precision mode, one fp16 product instead of the three of the hi/lo split.
+template <int KSTEPS, bool HP>   // K = 32 * KSTEPS = D_in * 128
 __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
     const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
             const int k8 = chunk * 2 + half, ks = k8 >> 2;
             const int slot = (k8 & 3) * 16 + row;      // A-fragment lane that consumes it
             xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = hi;
-            xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = lo;
+            if constexpr (!HP) xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = lo;
         }
     }
     __syncthreads();
@@ -156,17 +157,20 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 bh[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 0) * 64];
-                bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
+                if constexpr (!HP) bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
             }
 #pragma unroll
             for (int mt = 0; mt < kGemmMT; ++mt) {
                 const half8 ah = xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
-                const half8 al = xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
+                half8 al;
+                if constexpr (!HP) al = xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-                    acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                    acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                    if constexpr (!HP) {
+                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                    }
                 }
             }
         }

@@ -43,7 +43,9 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // MFMA rows zero -- free, the matrix pipe is not the limiter -- and halves the per-step VALU and
 // memory instruction count; it is used whenever 4-window tiles still fit the chip in one wave of
 // work-groups (B <= ~500).
-template <int PF, int NQ, bool XIN, int ABL = 0>
+// HP: half-precision mode (`TorchModel.half()`): fp16 operands without the hi/lo split -- one A
+// row per window (row 4g + q, up to NQ = 4 -> 16 windows per work-group), 12 MFMAs per wave.
+template <int PF, int NQ, bool XIN, bool HP, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -69,7 +71,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float c_sig = -inv_scale * 1.44269504088896340736f;
     const float c_tanh = 2.0f * inv_scale * 1.44269504088896340736f;
 
-    half8 wf[4][3][2];
+    constexpr int NS = HP ? 1 : 2;   // fp16 pieces per operand
+    static_assert(HP || NQ <= 2, "fp32-parity mode carries at most 2 windows per lane");
+    half8 wf[4][3][NS];
     {
         const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * 24) * 64 + lane;
 #pragma unroll
@@ -77,33 +81,34 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
+                for (int sp = 0; sp < NS; ++sp)
                     wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
-    half8 wx[3][2];
+    half8 wx[3][NS];
     if constexpr (XIN) {
         const half8 *wp = wxfrag + ((size_t)(d * 8 + w8) * 6) * 64 + lane;
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) wx[gate][sp] = wp[(size_t)(gate * 2 + sp) * 64];
+            for (int sp = 0; sp < NS; ++sp) wx[gate][sp] = wp[(size_t)(gate * 2 + sp) * 64];
     }
     for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
 
     const int u = 16 * w8 + c;
     const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
-    // which windows of which tile: NQ == 2 -> the whole tile (window 2g+q);
-    // NQ == 1 -> half tile h: window 4h + g, i.e. layout lane-group 2h + (g>>1), q = g&1
-    const int tile = (NQ == 2) ? blockIdx.x : (blockIdx.x >> 1);
+    // this work-group carries windows [4*NQ*blockIdx.x, +4*NQ); lane group g holds windows
+    // NQ*g + q of it.  Layout tiles are 8 windows (layout.hpp): window w -> tile w>>3,
+    // lane-group (w&7)>>1, q (w&7)&1.
     const long tstep = reverse ? -1 : 1;
     const int t_first = reverse ? (T - 1) : 0;
     const float *gp[NQ];
     float *op[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        int lq, llane;
-        if (NQ == 2) { lq = q; llane = lane; }
-        else { const int h = blockIdx.x & 1; lq = g & 1; llane = (2 * h + (g >> 1)) * 16 + c; }
+        int win = blockIdx.x * (4 * NQ) + NQ * g + q;
+        if (win >= n_tiles * kTileWin) win = n_tiles * kTileWin - 1;   // (only NQ = 4 can run past the padding)
+        const int tile = win >> 3, wt = win & 7;
+        const int llane = (wt >> 1) * 16 + c, lq = wt & 1;
         gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first) + gi_in_block(w8, lq, 0, llane);
         op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, lq, llane);
     }
@@ -115,7 +120,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
     for (int q = 0; q < NQ; ++q) hprev[q] = 0.f;
 
-    // rows of the A operand: 4g + 2q + {0: hi, 1: lo}; with NQ == 1 rows 4g+2, 4g+3 stay zero.
+    // rows of the A operand: fp32-parity mode 4g + 2q + {0: hi, 1: lo}; half mode 4g + q.
+    // Unused rows stay zero.
     // Prefetch ring, PF steps deep: gq[p][q*3 + gate] (or the packed x fragment xq[p]).  Primed
     // here and fully drained once (one HBM round trip per launch): the main loop is then entered
     // with nothing in flight, so hipcc's waitcnt pass sees the ring only in its steady-state issue
@@ -169,24 +175,24 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
+            for (int sp = 0; sp < NS; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
     if constexpr (XIN) {
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wx[gate][sp]));
+            for (int sp = 0; sp < NS; ++sp) asm volatile("" ::"v"(wx[gate][sp]));
     }
     asm volatile("" ::"v"(bhn));
     __syncthreads();
 
     floatx4 xar = floatx4{0.f, 0.f, 0.f, 0.f}, xaz = xar, xgn = xar;
     if constexpr (XIN && !(ABL & 1)) {
-        xar = mfma16(xq[0], wx[0][0], xar);
-        xaz = mfma16(xq[0], wx[1][0], xaz);
-        xgn = mfma16(xq[0], wx[2][0], xgn);
-        xar = mfma16(xq[0], wx[0][1], xar);
-        xaz = mfma16(xq[0], wx[1][1], xaz);
-        xgn = mfma16(xq[0], wx[2][1], xgn);
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            xar = mfma16(xq[0], wx[0][sp], xar);
+            xaz = mfma16(xq[0], wx[1][sp], xaz);
+            xgn = mfma16(xq[0], wx[2][sp], xgn);
+        }
     }
     // ABL & 64: per-phase cycle accounting with s_memtime (perturbs the schedule; debug only)
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
@@ -228,10 +234,11 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        ar = mfma16(a[ks], wf[ks][0][0], ar);
-                        az = mfma16(a[ks], wf[ks][1][0], az);
-                        ar = mfma16(a[ks], wf[ks][0][1], ar);
-                        az = mfma16(a[ks], wf[ks][1][1], az);
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp) {
+                            ar = mfma16(a[ks], wf[ks][0][sp], ar);
+                            az = mfma16(a[ks], wf[ks][1][sp], az);
+                        }
                     }
                 }
                 // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
@@ -246,23 +253,27 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
                         anh = mfma16(a[ks], wf[ks][2][0], anh);
-                        anl = mfma16(a[ks], wf[ks][2][1], anl);
+                        if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
                     }
                 }
+                // sum of this window's accumulator rows (hi + lo rows, or the single fp16 row)
+                auto rows = [&](const floatx4 &v, int q) {
+                    if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
+                };
                 float rr[NQ], zz[NQ], gnv[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     float gr, gz;
-                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = gin[2 * q] + gin[2 * q + 1]; }
+                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = rows(gin, q); }
                     else { gr = gq[p][q * 3]; gz = gq[p][q * 3 + 1]; gnv[q] = gq[p][q * 3 + 2]; }
-                    const float tr = XIN ? (ar[2 * q] + ar[2 * q + 1]) : ((gr + ar[2 * q]) + ar[2 * q + 1]);
-                    const float tz = XIN ? (az[2 * q] + az[2 * q + 1]) : ((gz + az[2 * q]) + az[2 * q + 1]);
+                    const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
+                    const float tz = XIN ? rows(az, q) : (gz + rows(az, q));
                     rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
                     zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
                 }
                 if constexpr (!(ABL & 1)) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < 4 * NS; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
                     }
@@ -273,13 +284,15 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if constexpr (ABL & 2) {
-                        const float h = ((ar[2 * q] + az[2 * q + 1]) + (anh[2 * q] + anl[2 * q + 1])) * 1e-6f +
+                        const float h = ((rows(ar, q) + rows(az, q)) + (rows(anh, q) + rows(anl, q))) * 1e-6f +
                                         (rr[q] + zz[q] + gnv[q]) * 1e-9f;
                         hprev[q] = h; hn[q] = h;
                         if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
                         continue;
                     }
-                    const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                    float tn;
+                    if constexpr (HP) tn = anh[q] + bhn;
+                    else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
                     const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
                     const float e = __builtin_amdgcn_exp2f(an * c_tanh);
                     const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
@@ -293,8 +306,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 for (int q = 0; q < NQ; ++q) {
                     _Float16 hi, lo;
                     split_f16(hn[q] * kActScale, hi, lo);
-                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
-                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                    if constexpr (HP) {
+                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
+                    } else {
+                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                    }
                     op[q] += ostride;
                 }
                 if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(4); }   // split + LDS write
@@ -307,9 +324,11 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     xar = mfma16(xn, wx[0][0], zero);
                     xaz = mfma16(xn, wx[1][0], zero);
                     xgn = mfma16(xn, wx[2][0], zero);
-                    xar = mfma16(xn, wx[0][1], xar);
-                    xaz = mfma16(xn, wx[1][1], xaz);
-                    xgn = mfma16(xn, wx[2][1], xgn);
+                    if constexpr (!HP) {
+                        xar = mfma16(xn, wx[0][1], xar);
+                        xaz = mfma16(xn, wx[1][1], xaz);
+                        xgn = mfma16(xn, wx[2][1], xgn);
+                    }
                 }
                 if constexpr (ABL & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 __global__ __launch_bounds__(256) void k_pack_x(
     const float *__restrict__ x,   // [B][T][I]
     half8 *__restrict__ xfrag,     // [n_wg][T][64]
-    int B, int T, int I, int nq, int n_wg, float sx, int *__restrict__ oor)
+    int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_wg * T * 64;
@@ -349,12 +368,12 @@ __global__ __launch_bounds__(256) void k_pack_x(
     const int t = (int)(wt % T);
     const int wg = (int)(wt / T);
     const int row = lane & 15, gq = lane >> 4;
-    const int g = row >> 2, split = row & 1;
-    int win;
-    bool live;
-    if (nq == 2) { win = wg * 8 + 2 * g + ((row >> 1) & 1); live = true; }
-    else { win = wg * 4 + g; live = ((row >> 1) & 1) == 0; }
-    live = live && (win < B);
+    // row -> (window slot q of lane-group g, hi|lo piece): fp32-parity 4g + 2q + split, half 4g + q
+    const int g = row >> 2;
+    const int q = hp ? (row & 3) : ((row >> 1) & 1);
+    const int split = hp ? 0 : (row & 1);
+    const int win = wg * 4 * nq + nq * g + q;
+    const bool live = (q < nq) && (win < B);
     half8 v;
     bool bad = false;
 #pragma unroll

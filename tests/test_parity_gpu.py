@@ -137,6 +137,33 @@ def test_out_of_range_input_takes_exact_projection(gold, engines):
     _check(engines("init").forward_host(x2), oracle.c_gru_forward(x2, weight_set(gold, "init")), what="after")
 
 
+def test_half_precision_mode(gold):
+    """`model.half()` path: fp16 operands, fp32 accumulate (what the reference runs on a GPU by
+    default, prediction.py:164-168).  Acceptance: within 2x of the deviation a CPU
+    fp16 emulation of the reference shows against fp32 (8.4e-4 on trained-like weights), argmax
+    essentially identical; the three work-group sizes compute identical results."""
+    x = synth.counts_windows(21, 800, seed=61)
+    for wname, tol in (("trained", 2e-3), ("x3", 2e-3)):
+        ref = oracle.c_gru_forward(x, weight_set(gold, wname))
+        outs = []
+        for tile in (4, 8, 16):
+            e = engine.GruEngine(weight_set(gold, wname))
+            e.set_precision(True)
+            e.set_option("rec_windows_per_tile", tile)
+            outs.append(e.forward_host(x))
+            e.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        err = np.abs(outs[0] - ref).max()
+        agree = (outs[0].argmax(-1) == ref.argmax(-1)).mean()
+        print(f"half precision {wname}: max|dp| = {err:.2e}, argmax agreement = {agree:.5f}")
+        assert err <= tol
+        srt = np.sort(ref, -1)
+        clear = (srt[..., -1] - srt[..., -2]) > 2 * tol      # positions the reference itself decides
+        assert (outs[0].argmax(-1) == ref.argmax(-1))[clear].all()
+        if wname == "trained":
+            assert agree >= 0.9999
+
+
 def test_empty_inputs(gold, engines):
     e = engines("init")
     assert e.forward_host(np.zeros((0, 10, 10), np.float32)).shape == (0, 10, 5)
