@@ -143,3 +143,50 @@ def test_synthetic_counts_contract():
     assert set(np.unique(y)) == {0, 1, 2, 3, 4}
     x2 = synth.counts_windows(3, 2000, depth=60, seed=5)
     assert np.array_equal(x, x2)                   # seeded
+
+
+# ---- integration hook against the UNMODIFIED reference (build container only) ----------------
+from oracle import ref_shim  # noqa: E402
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_integration_hook_keeps_reference_model_on_cpu(tmp_path):
+    """`integration.install()` wraps ModelStoreTGZ.load_model (datastore.py:135-157); a CPU load
+    (`medaka inference --cpu`) must come back as the reference's own model, untouched."""
+    import pickle
+    import sys
+    import tarfile
+    import types
+    import functools
+    ref_shim.install()
+    # datastore imports h5py lazily through module attributes only; the stub is enough
+    import medaka.datastore as ds
+    import medaka.models as ref_models
+    from medaka_amd import integration
+
+    # a model archive exactly as ModelMetaCheckpoint writes it (torch_ext.py:40-61):
+    # <top>/weights.pt + <top>/meta.pkl with a partial(model_from_dict, {...})
+    torch.manual_seed(1)
+    import medaka.architectures as arch
+    ref = arch.GRUModel(num_features=10, num_classes=5, gru_size=128)
+    top = tmp_path / "model"
+    top.mkdir()
+    torch.save(ref.state_dict(), top / "weights.pt")
+    meta = {"model_function": functools.partial(ref_models.model_from_dict, ref.to_dict())}
+    with open(top / "meta.pkl", "wb") as fh:
+        pickle.dump(meta, fh)
+    tgz = tmp_path / "toy_model_pt.tar.gz"
+    with tarfile.open(tgz, "w:gz") as tar:
+        tar.add(top, arcname="model")
+
+    integration.install()
+    try:
+        with ds.ModelStoreTGZ(str(tgz)) as store:
+            model = store.load_model(device=torch.device("cpu"))
+        assert type(model).__module__.startswith("medaka.architectures")   # reference class
+        assert type(model).__name__ == "GRUModel"
+        for k, v in ref.state_dict().items():
+            assert torch.equal(model.state_dict()[k], v)
+    finally:
+        integration.uninstall()
+    assert ds.ModelStoreTGZ.load_model.__name__ == "load_model"
