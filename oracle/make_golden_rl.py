@@ -1,0 +1,47 @@
+"""Goldens for the read-level model from the UNMODIFIED reference `LatentSpaceLSTM`
+(medaka/architectures/latent_space_lstm.py) on PyTorch-CPU.  Build container only.
+
+    python oracle/make_golden_rl.py   ->  tests/golden/rl_*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim, rl_oracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    arch, models, te = ref_shim.reference_modules()
+    out = {}
+    for name, kw in (("bi", dict()), ("uni", dict(bidirectional=False)), ("bi_dwells", dict(use_dwells=True))):
+        torch.manual_seed(7)
+        m = arch.LatentSpaceLSTM(**kw).eval()
+        # non-trivial batch-norm statistics and larger recurrent weights (default init is tame)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.endswith("running_mean"):
+                    v.copy_(torch.randn_like(v) * 0.3)
+                elif k.endswith("running_var"):
+                    v.copy_(torch.rand_like(v) + 0.5)
+                elif "convs.2.weight" in k or "convs.5.weight" in k:
+                    v.copy_(torch.rand_like(v) + 0.5)
+                elif "lstm" in k and "weight" in k:
+                    v.mul_(2.0)
+        state = {k: v.numpy().copy() for k, v in m.state_dict().items() if "num_batches_tracked" not in k}
+        np.savez(os.path.join(GOLD, f"rl_weights_{name}.npz"), **state)
+        x = rl_oracle.synth_reads(3, 120, 9, use_dwells=kw.get("use_dwells", False), seed=11)
+        y = m.predict_on_batch(te.Batch(read_level_features=torch.from_numpy(x))).numpy()
+        out[f"{name}/x"] = x
+        out[f"{name}/y"] = y
+        print(name, y.shape, float(np.abs(rl_oracle.rl_forward(x, state, **{k: v for k, v in kw.items()}) - y).max()))
+    np.savez_compressed(os.path.join(GOLD, "rl_cases.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
