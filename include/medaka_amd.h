@@ -131,6 +131,48 @@ int mdk_majority_forward_dev(const float *x_dev, long n_cols, float *probs_dev, 
                              void *stream);
 int mdk_majority_forward(const float *x_host, long n_cols, float *probs_host, int device);
 
+/* ------------------------------------------------------------------------------------------
+ * Read-level model (reference `LatentSpaceLSTM`, medaka/architectures/latent_space_lstm.py:35-207):
+ * Embedding + q-score (+ dwell) -> Conv1d(k=1) -> ReLU -> BN -> Conv1d(k=17) -> ReLU -> BN ->
+ * Linear -> masked mean over reads -> 2-layer bi-LSTM or 4 alternating LSTMs -> Linear -> softmax.
+ * Supported: lstm_size == cnn_size == 128, kernel_sizes [1, 17], embedding size 6, 5 classes.
+ */
+typedef struct mdk_rl mdk_rl;
+typedef struct {
+    int lstm_size;       /* 128 */
+    int cnn_size;        /* 128 */
+    int kernel_size0;    /* 1 */
+    int kernel_size1;    /* 17 */
+    int use_dwells;      /* 0/1: extra dwell feature, input has 5 bytes per read position */
+    int alphabet_size;   /* bases_alphabet_size, 6 */
+    int embedding_size;  /* bases_embedding_size, 6 */
+    int bidirectional;   /* 1: 2-layer bi-LSTM; 0: reverse-forward-reverse-forward stack */
+    int num_classes;     /* 5 */
+    int normalise;       /* 1: softmax */
+} mdk_rl_desc;
+
+/*
+ * `weights`: 34 host fp32 tensors in `state_dict()` order without `num_batches_tracked` and the
+ * unused `read_level_conv.expansion_layer.*`:
+ *   base_embedder.weight, strand_embedder.weight,
+ *   convs.0.{weight,bias}, convs.2.{weight,bias,running_mean,running_var},
+ *   convs.3.{weight,bias}, convs.5.{weight,bias,running_mean,running_var},
+ *   pre_pool_expansion_layer.{weight,bias},
+ *   16 LSTM tensors (weight_ih, weight_hh, bias_ih, bias_hh per layer/direction in state_dict order),
+ *   linear.{weight,bias}.
+ */
+int mdk_rl_create(const mdk_rl_desc *desc, const float *const *weights, int n_weights, int device,
+                  mdk_rl **out);
+/* Replaces `TorchModel.predict_on_batch` for ReadLevelFeaturesModel input
+ * (`batch.read_level_features`, base_classes.py:28-34): x uint8 (B, P, D, F) -> probs (B, P, 5). */
+int mdk_rl_forward(mdk_rl *m, const unsigned char *x_host, int B, int P, int D, int F, float *probs_host);
+int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int D, int F, float *probs_dev,
+                       void *stream);
+int mdk_rl_set_precision(mdk_rl *m, int precision);
+int mdk_rl_set_normalise(mdk_rl *m, int normalise);
+int mdk_rl_device(const mdk_rl *m);
+void mdk_rl_destroy(mdk_rl *m);
+
 /* Raw device helpers for hosts that do not carry their own HIP runtime binding (bench, tests). */
 int mdk_device_count(int *count);
 int mdk_device_name(int device, char *buf, size_t buflen);

@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MDK_LIB_OUT") or os.path.join(HERE, "libmedaka_amd.so")
-SOURCES = ["api.hip"]
-HEADERS = ["common.hpp", "rec_mfma.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
+SOURCES = ["api.hip", "rl_api.hip"]
+HEADERS = ["common.hpp", "layout.hpp", "host_common.hpp", "rec_mfma.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
+           "rl_front.hpp",
            os.path.join("..", "..", "include", "medaka_amd.h")]
 
 

@@ -8,7 +8,7 @@
 namespace mdk {
 
 // gi[d][m][n] = sum_k x[m][k] * w_ih_t[d][k][n] + bias[d][n];  one thread per (m, n)
-__global__ __launch_bounds__(128) void k_gi_exact(
+static __global__ __launch_bounds__(128) void k_gi_exact(
     const float *__restrict__ x, const float *__restrict__ w_ih_t, const float *__restrict__ bias,
     float *__restrict__ gi, long M, int K, size_t gi_dir_stride, const float *__restrict__ out_scale_p)
 {
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(128) void k_gi_exact(
 }
 
 // one 128-thread work-group per (window, direction); thread j owns hidden unit j
-__global__ __launch_bounds__(128) void k_rec_exact(
+static __global__ __launch_bounds__(128) void k_rec_exact(
     const float *__restrict__ gi,      // [D][M][384], folded bias
     const float *__restrict__ w_hh_t,  // [D][128][384]
     const float *__restrict__ b_hn,    // [D][128]

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(768) void k_gi_small(
     const float *xw = x + (size_t)(real ? win : 0) * T * K;
     const int t0 = blockIdx.z * t_per_block;
     const int t1 = min(T, t0 + t_per_block);
-    float *gout = gi + gi_block(d, n_tiles, tile, T, t0) + 4 * f4;
-    for (int t = t0; t < t1; ++t, gout += kGiBlock) {
+    float *gout = gi + gi_block(d, n_tiles, tile, T, t0, 3) + 4 * f4;
+    for (int t = t0; t < t1; ++t, gout += gi_block_floats(3)) {
         const float *xr = xw + (size_t)t * K;
         float4 acc = b;
         if (real) {
@@ -87,11 +87,12 @@ constexpr int kGemmSteps = 8;                  // time steps per work-group: M-t
 constexpr int kGemmMT = kGemmSteps / 2;        // 16-row MFMA tiles per M-tile
 
 // HP: half-precision mode, one fp16 product instead of the three of the hi/lo split.
-template <int KSTEPS, bool HP>   // K = 32 * KSTEPS = D_in * 128
+// NG = gate tiles per hidden unit (3 GRU, 4 LSTM): N = NG * 128 columns per direction.
+template <int KSTEPS, bool HP, int NG = 3>   // K = 32 * KSTEPS = D_in * 128
 __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
-    const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]
-    const float *__restrict__ bias,    // [D][384]
+    const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][NG gates][2 hi/lo][64 lanes]
+    const float *__restrict__ bias,    // [D][NG*128]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
     const float *__restrict__ out_scale_p)
@@ -144,20 +145,20 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     __syncthreads();
 
     for (int d = 0; d < D; ++d) {
-        floatx4 acc[kGemmMT][3];
+        floatx4 acc[kGemmMT][NG];
 #pragma unroll
         for (int mt = 0; mt < kGemmMT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NG; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
+        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * KSTEPS) * (2 * NG) * 64 + lane;
 #pragma unroll 1
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            half8 bh[3], bl[3];
+            half8 bh[NG], bl[NG];
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                bh[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 0) * 64];
-                if constexpr (!HP) bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
+            for (int nt = 0; nt < NG; ++nt) {
+                bh[nt] = wp[(size_t)((ks * NG + nt) * 2 + 0) * 64];
+                if constexpr (!HP) bl[nt] = wp[(size_t)((ks * NG + nt) * 2 + 1) * 64];
             }
 #pragma unroll
             for (int mt = 0; mt < kGemmMT; ++mt) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
                 half8 al;
                 if constexpr (!HP) al = xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt) {
+                for (int nt = 0; nt < NG; ++nt) {
                     acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
                     if constexpr (!HP) {
                         acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
         // ---- epilogue: scale back, add folded bias, 256-byte runs per accumulator register
         const float os = out_scale_p[d];
         const float inv_scale = inv_scale_p[d] * os;   // powers of two: exact
-        float bv[3];
+        float bv[NG];
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) bv[nt] = bias[(size_t)d * kG + nt * kH + 16 * w8 + (lane & 15)] * os;
-        float *gblk = gi + gi_block(d, n_tiles, tile, T, t0);
+        for (int nt = 0; nt < NG; ++nt) bv[nt] = bias[(size_t)d * (NG * kH) + nt * kH + 16 * w8 + (lane & 15)] * os;
+        float *gblk = gi + gi_block(d, n_tiles, tile, T, t0, NG);
 #pragma unroll
         for (int mt = 0; mt < kGemmMT; ++mt) {
 #pragma unroll
@@ -189,9 +190,9 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
                 const int q = r >> 1, tt = r & 1;
                 const int t = t0 + 2 * mt + tt;
                 if (t < T) {
-                    float *dst = gblk + (size_t)(2 * mt + tt) * kGiBlock + gi_in_block(w8, q, 0, lane);
+                    float *dst = gblk + (size_t)(2 * mt + tt) * gi_block_floats(NG) + gi_in_block(w8, q, 0, lane, NG);
 #pragma unroll
-                    for (int nt = 0; nt < 3; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
+                    for (int nt = 0; nt < NG; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
                 }
             }
         }

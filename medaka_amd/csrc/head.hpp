@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_head_tiled(
 }
 
 // channels a c g t A C G T d D -> classes [d+D, a+A, c+C, g+G, t+T]; class 0 += 1 - sum
-__global__ __launch_bounds__(256) void k_majority(const float *__restrict__ x,
+static __global__ __launch_bounds__(256) void k_majority(const float *__restrict__ x,
                                                   float *__restrict__ probs, long n_cols)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -6,7 +6,7 @@
 // layout made each of them four 64-byte runs 15 MB apart, and the kernel was bound by the number
 // of cache lines its vector-memory instructions touched, not by bytes):
 //
-//   gi_t  [dir][tile][t][w8 8][q 2][gate 3][lane 64]   fp32   3072 floats = 12 KB per block
+//   gi_t  [dir][tile][t][w8 8][q 2][gate NG][lane 64]  fp32   NG = 3 (GRU): 12 KB per block
 //   act_t [tile][t][dir][w8 8][q 2][lane 64]            fp32   D*1024 floats per block
 //
 // with  lane = g*16 + c,  window-in-tile = 2*g + q,  hidden unit = 16*w8 + c.
@@ -17,13 +17,14 @@
 namespace mdk {
 
 constexpr int kTileWin = 8;          // windows per tile
-constexpr int kGiBlock = 8 * 2 * 3 * 64;   // floats per (dir, tile, t) block of gi_t
+// NG = gate tiles per hidden unit: 3 for the GRU (r, z, n), 4 for the LSTM (i, f, g, o)
+__host__ __device__ inline constexpr int gi_block_floats(int NG) { return 8 * 2 * NG * 64; }
 
-__host__ __device__ inline size_t gi_block(int dir, int n_tiles, int tile, int T, int t) {
-    return (((size_t)dir * n_tiles + tile) * T + t) * kGiBlock;
+__host__ __device__ inline size_t gi_block(int dir, int n_tiles, int tile, int T, int t, int NG) {
+    return (((size_t)dir * n_tiles + tile) * T + t) * gi_block_floats(NG);
 }
-__host__ __device__ inline int gi_in_block(int w8, int q, int gate, int lane) {
-    return ((w8 * 2 + q) * 3 + gate) * 64 + lane;
+__host__ __device__ inline int gi_in_block(int w8, int q, int gate, int lane, int NG) {
+    return ((w8 * 2 + q) * NG + gate) * 64 + lane;
 }
 __host__ __device__ inline size_t act_block(int D, int tile, int T, int t) {
     return ((size_t)tile * T + t) * (size_t)(D * 1024);

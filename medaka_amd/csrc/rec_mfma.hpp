@@ -45,7 +45,9 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // work-groups (B <= ~500).
 // HP: half-precision mode (`TorchModel.half()`): fp16 operands without the hi/lo split -- one A
 // row per window (row 4g + q, up to NQ = 4 -> 16 windows per work-group), 12 MFMAs per wave.
-template <int PF, int NQ, bool XIN, bool HP, int ABL = 0>
+// CELL: 0 = GRU (3 gate tiles r,z,n), 1 = LSTM (4 gate tiles i,f,g,o; PyTorch nn.LSTM cell, used by
+// the read-level model, reference latent_space_lstm.py:129-149).
+template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -72,17 +74,20 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float c_tanh = 2.0f * inv_scale * 1.44269504088896340736f;
 
     constexpr int NS = HP ? 1 : 2;   // fp16 pieces per operand
+    constexpr int NG = CELL ? 4 : 3; // gate tiles per wave
+    static_assert(!(XIN && CELL), "the fused input projection exists for the GRU layer 0 only");
+    static_assert(!(CELL && ABL), "ablation builds exist for the GRU cell only");
     static_assert(HP || NQ <= 2, "fp32-parity mode carries at most 2 windows per lane");
-    half8 wf[4][3][NS];
+    half8 wf[4][NG][NS];
     {
-        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * 24) * 64 + lane;
+        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * (8 * NG)) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
+            for (int gate = 0; gate < NG; ++gate)
 #pragma unroll
                 for (int sp = 0; sp < NS; ++sp)
-                    wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
+                    wf[ks][gate][sp] = wp[(size_t)((ks * NG + gate) * 2 + sp) * 64];
     }
     half8 wx[3][NS];
     if constexpr (XIN) {
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
 
     const int u = 16 * w8 + c;
-    const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
+    const float bhn = CELL ? 0.f : b_hn[d * kH + u] * (1.0f / inv_scale);
     // this work-group carries windows [4*NQ*blockIdx.x, +4*NQ); lane group g holds windows
     // NQ*g + q of it.  Layout tiles are 8 windows (layout.hpp): window w -> tile w>>3,
     // lane-group (w&7)>>1, q (w&7)&1.
@@ -109,14 +114,14 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         if (win >= n_tiles * kTileWin) win = n_tiles * kTileWin - 1;   // (only NQ = 4 can run past the padding)
         const int tile = win >> 3, wt = win & 7;
         const int llane = (wt >> 1) * 16 + c, lq = wt & 1;
-        gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first) + gi_in_block(w8, lq, 0, llane);
+        gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first, NG) + gi_in_block(w8, lq, 0, llane, NG);
         op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, lq, llane);
     }
     const half8 *xp = xfrag + ((size_t)blockIdx.x * T + t_first) * 64 + lane;
-    const long gstride = tstep * kGiBlock;
+    const long gstride = tstep * gi_block_floats(NG);
     const long ostride = tstep * (long)(D * 1024);
     const long xstride = tstep * 64;
-    float hprev[NQ];
+    float hprev[NQ];   // GRU: h_{t-1};  LSTM: the cell state c_{t-1}
 #pragma unroll
     for (int q = 0; q < NQ; ++q) hprev[q] = 0.f;
 
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     // order and emits counted vmcnt(N >> 0) waits.  (A peeled / reordered priming sequence makes it
     // emit vmcnt(~0) in the first unrolled step of EVERY iteration = one exposed HBM latency per
     // PF steps.)
-    float gq[PF][3 * NQ];
+    float gq[PF][NG * NQ];
     half8 xq[PF];
     auto refill = [&](int p, bool advance) {
         if constexpr (XIN) {
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate)
-                    if constexpr (!(ABL & 8)) gq[p][q * 3 + gate] = gp[q][gate * 64]; else gq[p][q * 3 + gate] = 0.f;
+                for (int gate = 0; gate < NG; ++gate)
+                    if constexpr (!(ABL & 8)) gq[p][q * NG + gate] = gp[q][gate * 64]; else gq[p][q * NG + gate] = 0.f;
                 if (advance) gp[q] += gstride;   // stop advancing at the last row
             }
         }
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
         for (int i = 0; i < 8; ++i) xq[p][i] = (_Float16)0.f;
 #pragma unroll
-        for (int i = 0; i < 3 * NQ; ++i) gq[p][i] = 0.f;
+        for (int i = 0; i < NG * NQ; ++i) gq[p][i] = 0.f;
     }
     // slots 0..PF-2 hold steps 0..PF-2; slot PF-1 is filled during step 0 (for step PF-1): a slot
     // is always refilled one step after it was consumed, from inside the MFMA phase
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         if constexpr (XIN) asm volatile("" ::"v"(xq[p]));
         else {
 #pragma unroll
-            for (int i = 0; i < 3 * NQ; ++i) asm volatile("" ::"v"(gq[p][i]));
+            for (int i = 0; i < NG * NQ; ++i) asm volatile("" ::"v"(gq[p][i]));
         }
     }
 
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
+        for (int gate = 0; gate < NG; ++gate)
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
     if constexpr (XIN) {
@@ -223,83 +228,133 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
 
                 if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }   // LDS read latency
-                floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
-                if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
-                if constexpr (ABL & 1) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        ar[ks] = (float)a[ks][0]; az[ks] = (float)a[ks][2];
-                        anh[ks] = (float)a[ks][4]; anl[ks] = (float)a[ks][6];
-                    }
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                        for (int sp = 0; sp < NS; ++sp) {
-                            ar = mfma16(a[ks], wf[ks][0][sp], ar);
-                            az = mfma16(a[ks], wf[ks][1][sp], az);
-                        }
-                    }
-                }
-                // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
-                // vector-memory issue hides under the MFMAs; unconditional, in ring order
-                refill((p + PF - 1) % PF, (step + PF) < T);
-                // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
-                // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
-                // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
-                // after the last MFMA.
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 1)) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        anh = mfma16(a[ks], wf[ks][2][0], anh);
-                        if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
-                    }
-                }
                 // sum of this window's accumulator rows (hi + lo rows, or the single fp16 row)
                 auto rows = [&](const floatx4 &v, int q) {
                     if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
                 };
-                float rr[NQ], zz[NQ], gnv[NQ];
+                float hn[NQ];
+                if constexpr (CELL == 0) {
+                    floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
+                    if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
+                    if constexpr (ABL & 1) {
+    #pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            ar[ks] = (float)a[ks][0]; az[ks] = (float)a[ks][2];
+                            anh[ks] = (float)a[ks][4]; anl[ks] = (float)a[ks][6];
+                        }
+                    } else {
+    #pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+    #pragma unroll
+                            for (int sp = 0; sp < NS; ++sp) {
+                                ar = mfma16(a[ks], wf[ks][0][sp], ar);
+                                az = mfma16(a[ks], wf[ks][1][sp], az);
+                            }
+                        }
+                    }
+                    // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
+                    // vector-memory issue hides under the MFMAs; unconditional, in ring order
+                    refill((p + PF - 1) % PF, (step + PF) < T);
+                    // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
+                    // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
+                    // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
+                    // after the last MFMA.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(ABL & 1)) {
+    #pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            anh = mfma16(a[ks], wf[ks][2][0], anh);
+                            if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
+                        }
+                    }
+                    float rr[NQ], zz[NQ], gnv[NQ];
+    #pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float gr, gz;
+                        if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = rows(gin, q); }
+                        else { gr = gq[p][q * NG]; gz = gq[p][q * NG + 1]; gnv[q] = gq[p][q * NG + 2]; }
+                        const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
+                        const float tz = XIN ? rows(az, q) : (gz + rows(az, q));
+                        rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                        zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+                    }
+                    if constexpr (!(ABL & 1)) {
+    #pragma unroll
+                        for (int i = 0; i < 4 * NS; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    stamp(2);   // MFMA issue (+ sigmoids)
+    #pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if constexpr (ABL & 2) {
+                            const float h = ((rows(ar, q) + rows(az, q)) + (rows(anh, q) + rows(anl, q))) * 1e-6f +
+                                            (rr[q] + zz[q] + gnv[q]) * 1e-9f;
+                            hprev[q] = h; hn[q] = h;
+                            if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
+                            continue;
+                        }
+                        float tn;
+                        if constexpr (HP) tn = anh[q] + bhn;
+                        else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                        const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
+                        const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                        const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                        const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
+                        hprev[q] = h;
+                        hn[q] = h;
+                        if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
+                    }
+                } else {
+                    // ---- LSTM cell: i, f, g tiles first; the o tile last, with the cell update
+                    // (3 sigmoids/tanh, c = f c + i g, tanh c) interleaved under its MFMAs; only
+                    // sigmoid(o) * tanh(c) is exposed after the last MFMA.
+                    floatx4 ai = floatx4{0.f, 0.f, 0.f, 0.f}, af = ai, ag = ai, ao = ai;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    float gr, gz;
-                    if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = rows(gin, q); }
-                    else { gr = gq[p][q * 3]; gz = gq[p][q * 3 + 1]; gnv[q] = gq[p][q * 3 + 2]; }
-                    const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
-                    const float tz = XIN ? rows(az, q) : (gz + rows(az, q));
-                    rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
-                    zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
-                }
-                if constexpr (!(ABL & 1)) {
+                    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp) {
+                            ai = mfma16(a[ks], wf[ks][0][sp], ai);
+                            af = mfma16(a[ks], wf[ks][1][sp], af);
+                            ag = mfma16(a[ks], wf[ks][2][sp], ag);
+                        }
+                    }
+                    refill((p + PF - 1) % PF, (step + PF) < T);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp) ao = mfma16(a[ks], wf[ks][3][sp], ao);
+                    }
+                    float tc[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float ti = gq[p][q * NG + 0] + rows(ai, q);
+                        const float tf = gq[p][q * NG + 1] + rows(af, q);
+                        const float tg = gq[p][q * NG + 2] + rows(ag, q);
+                        const float iv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ti * c_sig));
+                        const float fv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tf * c_sig));
+                        const float gv = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tg * c_tanh)), 1.0f);
+                        const float cv = __builtin_fmaf(fv, hprev[q], iv * gv);
+                        hprev[q] = cv;
+                        tc[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * 2.88539008177792681472f)), 1.0f);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4 * NS; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                stamp(2);   // MFMA issue (+ sigmoids)
-                float hn[NQ];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if constexpr (ABL & 2) {
-                        const float h = ((rows(ar, q) + rows(az, q)) + (rows(anh, q) + rows(anl, q))) * 1e-6f +
-                                        (rr[q] + zz[q] + gnv[q]) * 1e-9f;
-                        hprev[q] = h; hn[q] = h;
-                        if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
-                        continue;
+                    for (int q = 0; q < NQ; ++q) {
+                        const float to = gq[p][q * NG + 3] + rows(ao, q);
+                        const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(to * c_sig));
+                        const float h = ov * tc[q];
+                        hn[q] = h;
+                        if (step < T) op[q][0] = h;
                     }
-                    float tn;
-                    if constexpr (HP) tn = anh[q] + bhn;
-                    else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                    const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
-                    const float e = __builtin_amdgcn_exp2f(an * c_tanh);
-                    const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                    const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
-                    hprev[q] = h;
-                    hn[q] = h;
-                    if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
                 }
                 if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain
 #pragma unroll
@@ -355,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 // LDS latency.  sx is chosen at load time so that (x*sx)(W_ih*swx) lands in the accumulator
 // scale S; inputs with |x| * sx beyond fp16 range raise `oor` and the engine falls back to the
 // exact fp32 projection kernel ON THE DEVICE (both paths are enqueued, the flag selects).
-__global__ __launch_bounds__(256) void k_pack_x(
+static __global__ __launch_bounds__(256) void k_pack_x(
     const float *__restrict__ x,   // [B][T][I]
     half8 *__restrict__ xfrag,     // [n_wg][T][64]
     int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor)

@@ -1,0 +1,387 @@
+// C ABI of the read-level model (reference `LatentSpaceLSTM`, medaka/architectures/
+// latent_space_lstm.py): fused read-level front end (rl_front.hpp) -> LSTM stack on the same
+// MFMA recurrence / projection kernels as the GRU model (CELL = 1, four gate tiles) -> head.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+#include "gi_proj.hpp"
+#include "head.hpp"
+#include "host_common.hpp"
+#include "layout.hpp"
+#include "rec_mfma.hpp"
+#include "rl_front.hpp"
+
+using namespace mdk;
+
+#ifndef MDK_PF
+#define MDK_PF 5
+#endif
+
+namespace {
+
+struct LstmLayer {
+    int K = 0, D = 1, reverse_mask = 0;
+    half8 *whh_frag = nullptr;   // [D][8][4][4][2][64]
+    half8 *wih_frag = nullptr;   // [D][8][K/32][4][2][64]
+    float *bias = nullptr;       // [D][512]  b_ih + b_hh
+    float *inv_rec = nullptr, *up_rec = nullptr, *inv_gi = nullptr;   // [D]
+};
+
+}  // namespace
+
+struct mdk_rl {
+    mdk_rl_desc desc{};
+    int device = 0;
+    int precision = MDK_PREC_FP32;
+    int opt_tile_windows = 0;
+    // front end
+    float *base_emb = nullptr, *strand_emb = nullptr, *w1 = nullptr, *b1 = nullptr, *a1 = nullptr, *c1 = nullptr;
+    half8 *w2frag = nullptr, *w3frag = nullptr;
+    float *b2 = nullptr, *a2 = nullptr, *c2 = nullptr, *b3 = nullptr;
+    float s1 = 1.f, inv2 = 1.f, s2 = 1.f, inv3 = 1.f;
+    int nf = 7;
+    // recurrent stack + head
+    std::vector<LstmLayer> layers;
+    float *lin_w = nullptr, *lin_b = nullptr;
+    // workspace
+    unsigned char *mask = nullptr;
+    int *nreads = nullptr;
+    size_t mask_cap = 0;
+    float *gi = nullptr, *act[2] = {nullptr, nullptr};
+    size_t ws_rows = 0;
+    unsigned char *x_dev = nullptr;
+    float *p_dev = nullptr;
+    size_t x_cap = 0, p_cap = 0;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" void mdk_rl_destroy(mdk_rl *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (void *p : {(void *)m->base_emb, (void *)m->strand_emb, (void *)m->w1, (void *)m->b1, (void *)m->a1,
+                    (void *)m->c1, (void *)m->w2frag, (void *)m->w3frag, (void *)m->b2, (void *)m->a2,
+                    (void *)m->c2, (void *)m->b3, (void *)m->lin_w, (void *)m->lin_b, (void *)m->mask,
+                    (void *)m->nreads, (void *)m->gi, (void *)m->act[0], (void *)m->act[1], (void *)m->x_dev,
+                    (void *)m->p_dev})
+        free_dev(p);
+    for (auto &L : m->layers) {
+        free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.bias);
+        free_dev(L.inv_rec); free_dev(L.up_rec); free_dev(L.inv_gi);
+    }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static int build_lstm_layer(LstmLayer &Ld, int K, int D, int reverse_mask, const float *const *w) {
+    constexpr int NG = 4, G4 = 4 * kH;
+    Ld.K = K; Ld.D = D; Ld.reverse_mask = reverse_mask;
+    const int KS = K / 32;
+    std::vector<half8> whh((size_t)D * 8 * 4 * NG * 2 * 64), wih((size_t)D * 8 * KS * NG * 2 * 64);
+    std::vector<float> bias((size_t)D * G4), inv_rec(D), up_rec(D), inv_gi(D);
+    for (int d = 0; d < D; ++d) {
+        const float *w_ih = w[4 * d + 0], *w_hh = w[4 * d + 1], *b_ih = w[4 * d + 2], *b_hh = w[4 * d + 3];
+        for (int j = 0; j < G4; ++j) bias[(size_t)d * G4 + j] = b_ih[j] + b_hh[j];
+        const float sw = pick_scale(w_hh, (size_t)G4 * kH);
+        inv_rec[d] = 1.0f / (kActScale * sw);
+        up_rec[d] = kActScale * sw;
+        const float swi = pick_scale(w_ih, (size_t)G4 * K);
+        inv_gi[d] = 1.0f / (kActScale * swi);
+        for (int w8 = 0; w8 < 8; ++w8)
+            for (int gate = 0; gate < NG; ++gate)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = gate * kH + 16 * w8 + (lane & 15), gq = lane >> 4;
+                    for (int ks = 0; ks < 4; ++ks) {
+                        half8 hi, lo;
+                        for (int i = 0; i < 8; ++i) {
+                            _Float16 a, b;
+                            split_host(w_hh[(size_t)j * kH + 32 * ks + 8 * gq + i] * sw, a, b);
+                            hi[i] = a; lo[i] = b;
+                        }
+                        const size_t base = ((((size_t)(d * 8 + w8) * 4 + ks) * NG + gate) * 2) * 64 + lane;
+                        whh[base] = hi; whh[base + 64] = lo;
+                    }
+                    for (int ks = 0; ks < KS; ++ks) {
+                        half8 hi, lo;
+                        for (int i = 0; i < 8; ++i) {
+                            _Float16 a, b;
+                            split_host(w_ih[(size_t)j * K + 32 * ks + 8 * gq + i] * swi, a, b);
+                            hi[i] = a; lo[i] = b;
+                        }
+                        const size_t base = ((((size_t)(d * 8 + w8) * KS + ks) * NG + gate) * 2) * 64 + lane;
+                        wih[base] = hi; wih[base + 64] = lo;
+                    }
+                }
+    }
+    int rc;
+    if ((rc = upload(&Ld.whh_frag, whh))) return rc;
+    if ((rc = upload(&Ld.wih_frag, wih))) return rc;
+    if ((rc = upload(&Ld.bias, bias))) return rc;
+    if ((rc = upload(&Ld.inv_rec, inv_rec))) return rc;
+    if ((rc = upload(&Ld.up_rec, up_rec))) return rc;
+    if ((rc = upload(&Ld.inv_gi, inv_gi))) return rc;
+    return MDK_OK;
+}
+
+extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int n_weights, int device,
+                             mdk_rl **out) {
+    if (!desc || !w || !out) return fail(MDK_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (desc->lstm_size != kH || desc->cnn_size != kRlC)
+        return fail(MDK_ERR_ARG, "unsupported lstm_size %d / cnn_size %d (engine supports 128 / 128)",
+                    desc->lstm_size, desc->cnn_size);
+    if (desc->kernel_size0 != 1 || desc->kernel_size1 != kRlTaps)
+        return fail(MDK_ERR_ARG, "unsupported kernel_sizes [%d, %d] (engine supports [1, 17])",
+                    desc->kernel_size0, desc->kernel_size1);
+    if (desc->embedding_size != 6 || desc->alphabet_size < 1 || desc->alphabet_size > 8)
+        return fail(MDK_ERR_ARG, "unsupported embedding %d x %d", desc->alphabet_size, desc->embedding_size);
+    if (desc->num_classes != 5) return fail(MDK_ERR_ARG, "unsupported num_classes %d", desc->num_classes);
+    if (n_weights != 34) return fail(MDK_ERR_ARG, "expected 34 weight tensors, got %d", n_weights);
+    for (int i = 0; i < n_weights; ++i)
+        if (!w[i]) return fail(MDK_ERR_ARG, "weight tensor %d is null", i);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(MDK_ERR_DEVICE, "device %d not available (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mdk_rl *m = new mdk_rl();
+    m->desc = *desc;
+    m->device = device;
+    int rc = MDK_OK;
+    auto bail = [&](int code) { mdk_rl_destroy(m); return code; };
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
+    const int nf = 6 + 1 + (desc->use_dwells ? 1 : 0);
+    m->nf = nf;
+    const int A = desc->alphabet_size;
+    const float eps = 1e-5f;
+
+    // ---- front end: embeddings, conv1 (rows padded to 8 features), BN folded to a*x + c
+    {
+        std::vector<float> be(w[0], w[0] + A * 6), se(w[1], w[1] + 18), w1(128 * 8, 0.f);
+        for (int c = 0; c < 128; ++c)
+            for (int f = 0; f < nf; ++f) w1[c * 8 + f] = w[2][(size_t)c * nf + f];
+        std::vector<float> b1(w[3], w[3] + 128), a1(128), c1(128), b2(w[9], w[9] + 128), a2(128), c2(128),
+            b3(w[15], w[15] + 128);
+        for (int c = 0; c < 128; ++c) {
+            a1[c] = w[4][c] / std::sqrt(w[7][c] + eps);
+            c1[c] = w[5][c] - w[6][c] * a1[c];
+            a2[c] = w[10][c] / std::sqrt(w[13][c] + eps);
+            c2[c] = w[11][c] - w[12][c] * a2[c];
+        }
+        // analytic bounds -> operand scales.  |feature| <= max|emb_b| + max|emb_s|, 9.2 (q), 255 (dwell)
+        float eb = 0.f, es = 0.f;
+        for (float v : be) eb = std::max(eb, std::fabs(v));
+        for (float v : se) es = std::max(es, std::fabs(v));
+        float y1max = 0.f;
+        for (int c = 0; c < 128; ++c) {
+            float bound = std::fabs(b1[c]);
+            for (int f = 0; f < nf; ++f) {
+                const float fm = f < 6 ? (eb + es) : (f == 6 ? 9.2f : 255.f);
+                bound += std::fabs(w1[c * 8 + f]) * fm;
+            }
+            y1max = std::max(y1max, std::max(std::fabs(c1[c]), std::fabs(a1[c] * bound + c1[c])));
+        }
+        m->s1 = pick_scale_max(y1max);
+        const float sw2 = pick_scale(w[8], (size_t)128 * 128 * kRlTaps);
+        m->inv2 = 1.0f / (m->s1 * sw2);
+        float y2max = 0.f;
+        for (int co = 0; co < 128; ++co) {
+            float bound = std::fabs(b2[co]);
+            for (size_t i = 0; i < (size_t)128 * kRlTaps; ++i) bound += std::fabs(w[8][(size_t)co * 128 * kRlTaps + i]) * y1max;
+            y2max = std::max(y2max, std::max(std::fabs(c2[co]), std::fabs(a2[co] * bound + c2[co])));
+        }
+        m->s2 = pick_scale_max(y2max);
+        const float sw3 = pick_scale(w[14], (size_t)128 * 128);
+        m->inv3 = 1.0f / (m->s2 * sw3);
+        // conv2 B-fragments [17][4 kb][4 waves][2 nt][2][64]: W2[co][ci][tau]
+        std::vector<half8> w2f((size_t)kRlTaps * 4 * 4 * 2 * 2 * 64), w3f((size_t)4 * 4 * 2 * 2 * 64);
+        for (int tau = 0; tau < kRlTaps; ++tau)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = 32 * wv + 16 * nt + (lane & 15), gq = lane >> 4;
+                            half8 hi, lo;
+                            for (int i = 0; i < 8; ++i) {
+                                const int ci = 32 * kb + 8 * gq + i;
+                                _Float16 a, b;
+                                split_host(w[8][((size_t)co * 128 + ci) * kRlTaps + tau] * sw2, a, b);
+                                hi[i] = a; lo[i] = b;
+                            }
+                            const size_t base = (((((size_t)tau * 4 + kb) * 4 + wv) * 2 + nt) * 2) * 64 + lane;
+                            w2f[base] = hi; w2f[base + 64] = lo;
+                        }
+        for (int ks = 0; ks < 4; ++ks)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int j = 32 * wv + 16 * nt + (lane & 15), gq = lane >> 4;
+                        half8 hi, lo;
+                        for (int i = 0; i < 8; ++i) {
+                            _Float16 a, b;
+                            split_host(w[14][(size_t)j * 128 + 32 * ks + 8 * gq + i] * sw3, a, b);
+                            hi[i] = a; lo[i] = b;
+                        }
+                        const size_t base = ((((size_t)ks * 4 + wv) * 2 + nt) * 2) * 64 + lane;
+                        w3f[base] = hi; w3f[base + 64] = lo;
+                    }
+        if ((rc = upload(&m->base_emb, be)) || (rc = upload(&m->strand_emb, se)) || (rc = upload(&m->w1, w1)) ||
+            (rc = upload(&m->b1, b1)) || (rc = upload(&m->a1, a1)) || (rc = upload(&m->c1, c1)) ||
+            (rc = upload(&m->w2frag, w2f)) || (rc = upload(&m->b2, b2)) || (rc = upload(&m->a2, a2)) ||
+            (rc = upload(&m->c2, c2)) || (rc = upload(&m->w3frag, w3f)) || (rc = upload(&m->b3, b3)))
+            return bail(rc);
+    }
+    // ---- LSTM stack
+    if (desc->bidirectional) {
+        m->layers.resize(2);
+        if ((rc = build_lstm_layer(m->layers[0], 128, 2, 2, w + 16))) return bail(rc);
+        if ((rc = build_lstm_layer(m->layers[1], 256, 2, 2, w + 24))) return bail(rc);
+    } else {
+        m->layers.resize(4);   // reverse - forward - reverse - forward (latent_space_lstm.py:141-149)
+        for (int i = 0; i < 4; ++i)
+            if ((rc = build_lstm_layer(m->layers[i], 128, 1, (i % 2 == 0) ? 1 : 0, w + 16 + 4 * i))) return bail(rc);
+    }
+    {
+        const int Dl = desc->bidirectional ? 2 : 1;
+        std::vector<float> lw(w[32], w[32] + (size_t)5 * Dl * kH), lb(w[33], w[33] + 5);
+        if ((rc = upload(&m->lin_w, lw)) || (rc = upload(&m->lin_b, lb))) return bail(rc);
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
+    *out = m;
+    return MDK_OK;
+}
+
+extern "C" int mdk_rl_set_precision(mdk_rl *m, int precision) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (precision != MDK_PREC_FP32 && precision != MDK_PREC_FP16) return fail(MDK_ERR_ARG, "bad precision %d", precision);
+    m->precision = precision;
+    return MDK_OK;
+}
+extern "C" int mdk_rl_set_normalise(mdk_rl *m, int normalise) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    m->desc.normalise = normalise ? 1 : 0;
+    return MDK_OK;
+}
+extern "C" int mdk_rl_device(const mdk_rl *m) { return m ? m->device : -1; }
+
+static int rl_workspace(mdk_rl *m, int B, int Dp, size_t rows) {
+    if ((size_t)B * Dp > m->mask_cap) {
+        free_dev(m->mask); free_dev(m->nreads); m->mask = nullptr; m->nreads = nullptr; m->mask_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->mask, (size_t)B * Dp));
+        HIP_TRY(hipMalloc((void **)&m->nreads, (size_t)B * sizeof(int)));
+        m->mask_cap = (size_t)B * Dp;
+    }
+    if (rows > m->ws_rows) {
+        free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
+        m->gi = m->act[0] = m->act[1] = nullptr; m->ws_rows = 0;
+        HIP_TRY(hipMalloc((void **)&m->gi, (size_t)2 * rows * 4 * kH * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->act[0], rows * 2 * kH * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->act[1], rows * 2 * kH * sizeof(float)));
+        m->ws_rows = rows;
+    }
+    return MDK_OK;
+}
+
+extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                                  float *probs_dev, void *stream) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || P < 0 || Dp < 0) return fail(MDK_ERR_ARG, "negative shape");
+    if (B == 0 || P == 0) return MDK_OK;
+    if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
+    if (Dp < 1 || Dp > 256) return fail(MDK_ERR_ARG, "read depth %d outside 1..256", Dp);
+    const int need_f = m->desc.use_dwells ? 5 : 4;
+    if (F < need_f) return fail(MDK_ERR_ARG, "expected >= %d features per read position, got %d", need_f, F);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int T = P, n_tiles = (B + kTileWin - 1) / kTileWin;
+    const size_t rows = (size_t)n_tiles * kTileWin * T;
+    int rc = rl_workspace(m, B, Dp, rows);
+    if (rc) return rc;
+    const bool hp = (m->precision == MDK_PREC_FP16);
+
+    // ---- front end -> pooled (act[0], tile-major, one "direction")
+    HIP_TRY(hipMemsetAsync(m->act[0], 0, rows * kH * sizeof(float), s));   // padding windows of the last tile
+    hipLaunchKernelGGL(k_rl_mask, dim3(B), dim3(256), 0, s, x_dev, P, Dp, F, m->mask, m->nreads);
+    RlFrontArgs fa;
+    fa.x = x_dev; fa.mask = m->mask; fa.nreads = m->nreads; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
+    fa.w1 = m->w1; fa.b1 = m->b1; fa.a1 = m->a1; fa.c1 = m->c1; fa.w2frag = m->w2frag; fa.b2 = m->b2; fa.a2 = m->a2;
+    fa.c2 = m->c2; fa.w3frag = m->w3frag; fa.b3 = m->b3; fa.pooled = m->act[0];
+    fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
+    fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
+    hipLaunchKernelGGL(k_rl_front, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+
+    // ---- LSTM stack
+    const int n_win = n_tiles * kTileWin;
+    const float *in = m->act[0];
+    int din = 1;
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+        const LstmLayer &Ld = m->layers[l];
+        float *outp = m->act[(l + 1) & 1];
+        const int D = Ld.D;
+        int nq = 1;
+        while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > 256) nq *= 2;
+        if (m->opt_tile_windows == 4) nq = 1;
+        if (m->opt_tile_windows == 8) nq = 2;
+        if (m->opt_tile_windows == 16 && hp) nq = 4;
+        const dim3 rgrid((n_win + 4 * nq - 1) / (4 * nq), D);
+        const dim3 ggrid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
+#define MDK_GEMM(KS, HPF)                                                                          \
+    hipLaunchKernelGGL((k_gi_gemm<KS, HPF, 4>), ggrid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
+                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec)
+        if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
+        else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
+#undef MDK_GEMM
+#define MDK_REC(NQV, HPF)                                                                          \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, false, HPF, 1, 0>), rgrid, dim3(512), 0, s, m->gi, \
+                       (const half8 *)nullptr, (const half8 *)nullptr, Ld.whh_frag, Ld.bias, outp, n_tiles, T, D, \
+                       Ld.inv_rec, Ld.reverse_mask, (const int *)nullptr, 0)
+        if (hp) { if (nq == 1) MDK_REC(1, true); else if (nq == 2) MDK_REC(2, true); else MDK_REC(4, true); }
+        else { if (nq == 1) MDK_REC(1, false); else MDK_REC(2, false); }
+#undef MDK_REC
+        in = outp;
+        din = D;
+    }
+    // ---- head
+    {
+        const long n_blocks = (long)n_tiles * T;
+        const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
+        if (din == 2)
+            hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
+                               probs_dev, B, T, n_tiles, m->desc.normalise);
+        else
+            hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
+                               probs_dev, B, T, n_tiles, m->desc.normalise);
+    }
+    HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+extern "C" int mdk_rl_forward(mdk_rl *m, const unsigned char *x_host, int B, int P, int Dp, int F,
+                              float *probs_host) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || P < 0 || Dp < 0) return fail(MDK_ERR_ARG, "negative shape");
+    if (B == 0 || P == 0) return MDK_OK;
+    if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t nx = (size_t)B * P * Dp * F, np = (size_t)B * P * 5;
+    if (nx > m->x_cap) {
+        free_dev(m->x_dev); m->x_dev = nullptr; m->x_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->x_dev, nx));
+        m->x_cap = nx;
+    }
+    if (np > m->p_cap) {
+        free_dev(m->p_dev); m->p_dev = nullptr; m->p_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->p_dev, np * sizeof(float)));
+        m->p_cap = np;
+    }
+    HIP_TRY(hipMemcpyAsync(m->x_dev, x_host, nx, hipMemcpyHostToDevice, m->stream));
+    int rc = mdk_rl_forward_dev(m, m->x_dev, B, P, Dp, F, m->p_dev, m->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return MDK_OK;
+}

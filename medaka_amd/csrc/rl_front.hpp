@@ -1,0 +1,258 @@
+// Read-level front end of `LatentSpaceLSTM` (reference medaka/architectures/latent_space_lstm.py:
+// 154-196 and read_level_modules.py:7-100):
+//
+//   uint8 (B, P, D, F) -> Embedding(base) + Embedding(strand+1) (+) q/25-1 (+ dwell)     7|8 features
+//   -> Conv1d(k=1) -> ReLU -> BatchNorm1d -> Conv1d(k=17, pad 8) -> ReLU -> BatchNorm1d  (per read)
+//   -> Linear(128 -> 128) -> mean over the non-empty reads                               (B, P, 128)
+//
+// One fused kernel, nothing per-read is ever written to HBM (the per-read activations would be
+// 512 B x B x D x P).  A work-group owns (window b, 64 positions) and walks the reads:
+//   1. features + conv1 + ReLU + BN for 80 positions (8 halo each side) straight into LDS as the
+//      fp16 hi/lo A operand of conv2 (zero outside the window = the zero padding of conv2);
+//   2. conv2 as an implicit GEMM on the matrix cores: M = 64 positions, N = 128 channels,
+//      K = 17 taps x 128 channels = 68 k-steps; the A fragment of tap tau is the same LDS tile
+//      read tau rows further down; W2 B-fragments stream from L2 (pre-packed);
+//   3. bias + ReLU + BN in registers, re-split into LDS, Linear(128->128) as a second small MFMA
+//      GEMM, accumulated over reads in registers (empty reads are skipped: their mask is 0);
+//   4. mean, bias, store in the tile-major activation layout the LSTM projection GEMM reads.
+// fp32 parity through the same fp16 hi/lo split as the GRU kernels (three products, fp32
+// accumulate); BatchNorm is folded to y = a*x + c at load time (eval mode).
+#pragma once
+#include "common.hpp"
+#include "layout.hpp"
+
+namespace mdk {
+
+constexpr int kRlPos = 64;                       // positions per work-group
+constexpr int kRlHalo = 8;                       // (17 - 1) / 2
+constexpr int kRlRows = kRlPos + 2 * kRlHalo;    // 80 rows of conv1 output per tile
+constexpr int kRlRowBytes = 272;                 // 128 channels x 2 B + 16 B pad (bank spread)
+constexpr int kRlTaps = 17;
+constexpr int kRlC = 128;                        // cnn_size == lstm_size == 128
+
+// mask[b][d] = any non-zero byte of read d in window b (latent_space_lstm.py:164-166);
+// nreads[b] = number of non-empty reads.  One work-group per window.
+static __global__ __launch_bounds__(256) void k_rl_mask(const unsigned char *__restrict__ x, int P, int Dp, int F,
+                                                 unsigned char *__restrict__ mask, int *__restrict__ nreads)
+{
+    __shared__ int flags[256];
+    const int b = blockIdx.x;
+    const unsigned char *xb = x + (size_t)b * P * Dp * F;
+    for (int d = threadIdx.x; d < 256; d += blockDim.x) flags[d] = 0;
+    __syncthreads();
+    const size_t n = (size_t)P * Dp * F;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        if (xb[i] != 0) {
+            const int d = (int)((i / F) % Dp);
+            flags[d] = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int d = 0; d < Dp; ++d) { mask[(size_t)b * Dp + d] = (unsigned char)flags[d]; cnt += flags[d]; }
+        nreads[b] = cnt;
+    }
+}
+
+struct RlFrontArgs {
+    const unsigned char *x;        // [B][P][Dp][F]
+    const unsigned char *mask;     // [B][Dp]
+    const int *nreads;             // [B]
+    const float *base_emb;         // [A][6]
+    const float *strand_emb;       // [3][6]
+    const float *w1;               // [128][8]  conv1 weights, rows padded to 8 features
+    const float *b1, *a1, *c1;     // [128] conv1 bias, BN1 scale, BN1 shift
+    const half8 *w2frag;           // [17][4 kb][4 waves][2 nt][2 hi/lo][64]
+    const float *b2, *a2, *c2;     // [128]
+    const half8 *w3frag;           // [4 ks][4 waves][2 nt][2 hi/lo][64]
+    const float *b3;               // [128]
+    float *pooled;                 // act_t layout, D = 1
+    int B, P, Dp, F, nf, n_alpha;
+    float s1, inv2, s2, inv3;      // operand scales (powers of two)
+};
+
+static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];   // 43.5 KB
+    __shared__ float feat[kRlRows][8];
+    __shared__ int fvalid[kRlRows];
+    __shared__ float emb_b[8][6], emb_s[3][6];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * kRlPos;
+    const int n = lane & 15, g = lane >> 4;
+
+    if (tid < A.n_alpha * 6) emb_b[tid / 6][tid % 6] = A.base_emb[tid];
+    if (tid >= 64 && tid < 64 + 18) emb_s[(tid - 64) / 6][(tid - 64) % 6] = A.strand_emb[tid - 64];
+
+    // conv1 row of this thread's channel
+    const int ci = tid & 127, rsel = tid >> 7;
+    float w1r[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) w1r[f] = A.w1[ci * 8 + f];
+    const float b1v = A.b1[ci], a1v = A.a1[ci], c1v = A.c1[ci];
+    // epilogue constants of this lane's conv2 / linear output columns: co = 32w + 16nt + n
+    float b2v[2], a2v[2], c2v[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = 32 * w + 16 * nt + n;
+        b2v[nt] = A.b2[co]; a2v[nt] = A.a2[co]; c2v[nt] = A.c2[co];
+    }
+    floatx4 pool[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) pool[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const unsigned char *xb = A.x + (size_t)b * A.P * A.Dp * A.F;
+    unsigned char *yhi = ytile, *ylo = ytile + kRlRows * kRlRowBytes;
+
+    for (int d = 0; d < A.Dp; ++d) {
+        if (A.mask[(size_t)b * A.Dp + d] == 0) continue;   // uniform: empty reads contribute 0
+        // ---- 1a. features of the 80 positions
+        if (tid < kRlRows) {
+            const int pp = p0 - kRlHalo + tid;
+            const bool ok = pp >= 0 && pp < A.P;
+            fvalid[tid] = ok;
+            float fv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const unsigned char *xr = xb + ((size_t)pp * A.Dp + d) * A.F;
+                int bi = xr[0];
+                if (bi >= A.n_alpha) bi = A.n_alpha - 1;
+                int si = (int)(signed char)xr[2] + 1;        // strand -1/0/+1 -> 0/1/2
+                si = si < 0 ? 0 : (si > 2 ? 2 : si);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) fv[e] = emb_b[bi][e] + emb_s[si][e];
+                fv[6] = (float)xr[1] / 25.0f - 1.0f;
+                if (A.nf == 8) fv[7] = (float)xr[4];
+            }
+#pragma unroll
+            for (int f = 0; f < 8; ++f) feat[tid][f] = fv[f];
+        }
+        __syncthreads();
+        // ---- 1b. conv1 (k=1) + ReLU + BN1 -> fp16 hi/lo tile
+        for (int r = rsel; r < kRlRows; r += 2) {
+            float v = b1v;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) v = fmaf(w1r[f], feat[r][f], v);
+            v = fmaxf(v, 0.f);
+            v = fmaf(a1v, v, c1v);
+            if (!fvalid[r]) v = 0.f;                         // zero padding of conv2's input
+            _Float16 hi, lo;
+            split_f16(v * A.s1, hi, lo);
+            *reinterpret_cast<_Float16 *>(yhi + r * kRlRowBytes + ci * 2) = hi;
+            *reinterpret_cast<_Float16 *>(ylo + r * kRlRowBytes + ci * 2) = lo;
+        }
+        __syncthreads();
+        // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks
+        floatx4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const half8 *wp = A.w2frag + (size_t)w * 4 * 64 + lane;
+#pragma unroll 1
+        for (int tau = 0; tau < kRlTaps; ++tau) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                half8 bh[2], bl[2];
+                const half8 *wk = wp + (size_t)(tau * 4 + kb) * (4 * 4 * 64);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    bh[nt] = wk[(nt * 2 + 0) * 64];
+                    bl[nt] = wk[(nt * 2 + 1) * 64];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int off = (16 * mt + n + tau) * kRlRowBytes + (32 * kb + 8 * g) * 2;
+                    const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
+                    const half8 al = *reinterpret_cast<const half8 *>(ylo + off);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // everybody is done reading the conv1 tile
+        // ---- 3a. bias + ReLU + BN2, re-split as the A operand of the linear layer
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(acc[mt][nt][r], A.inv2, b2v[nt]);
+                    v = fmaxf(v, 0.f);
+                    v = fmaf(a2v[nt], v, c2v[nt]);
+                    _Float16 hi, lo;
+                    split_f16(v * A.s2, hi, lo);
+                    const int row = 16 * mt + 4 * g + r, co = 32 * w + 16 * nt + n;
+                    *reinterpret_cast<_Float16 *>(yhi + row * kRlRowBytes + co * 2) = hi;
+                    *reinterpret_cast<_Float16 *>(ylo + row * kRlRowBytes + co * 2) = lo;
+                }
+        __syncthreads();
+        // ---- 3b. Linear(128 -> 128), accumulated over reads
+        floatx4 acc3[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc3[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 bh[2], bl[2];
+            const half8 *wk = A.w3frag + ((size_t)(ks * 4 + w) * 4) * 64 + lane;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bh[nt] = wk[(nt * 2 + 0) * 64];
+                bl[nt] = wk[(nt * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int off = (16 * mt + n) * kRlRowBytes + (32 * ks + 8 * g) * 2;
+                const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
+                const half8 al = *reinterpret_cast<const half8 *>(ylo + off);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc3[mt][nt] = mfma16(ah, bh[nt], acc3[mt][nt]);
+                    acc3[mt][nt] = mfma16(al, bh[nt], acc3[mt][nt]);
+                    acc3[mt][nt] = mfma16(ah, bl[nt], acc3[mt][nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pool[mt][nt][r] = fmaf(acc3[mt][nt][r], A.inv3, pool[mt][nt][r]);
+        __syncthreads();   // the tile is rewritten by the next read
+    }
+
+    // ---- 4. mean over reads + bias, tile-major store (window b = tile b>>3, slot (b&7))
+    const float inv_n = 1.0f / (float)A.nreads[b];   // 0 reads -> inf/nan, as the reference's 0/0
+    const int tile = b >> 3, wt = b & 7, gl = wt >> 1, ql = wt & 1;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 32 * w + 16 * nt + n;          // output feature
+        const float b3v = A.b3[j];
+        const int w8 = j >> 4, c = j & 15;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = p0 + 16 * mt + 4 * g + r;
+                if (t < A.P)
+                    A.pooled[act_block(1, tile, A.P, t) + act_in_block(0, w8, ql, gl * 16 + c)] =
+                        fmaf(pool[mt][nt][r], inv_n, b3v);
+            }
+    }
+}
+
+}  // namespace mdk

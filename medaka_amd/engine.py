@@ -145,6 +145,80 @@ class GruEngine:
             pass
 
 
+def rl_state_keys(bidirectional=True):
+    """state_dict keys of reference LatentSpaceLSTM in the order `mdk_rl_create` expects."""
+    keys = ["base_embedder.weight", "strand_embedder.weight"]
+    for conv, bn in ((0, 2), (3, 5)):
+        keys += [f"read_level_conv.convs.{conv}.weight", f"read_level_conv.convs.{conv}.bias"]
+        keys += [f"read_level_conv.convs.{bn}.{n}" for n in ("weight", "bias", "running_mean", "running_var")]
+    keys += ["pre_pool_expansion_layer.weight", "pre_pool_expansion_layer.bias"]
+    if bidirectional:
+        for layer in range(2):
+            for sfx in ("", "_reverse"):
+                keys += [f"lstm.{n}_l{layer}{sfx}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    else:
+        for i in range(4):
+            keys += [f"lstm.{i}.lstm.{n}_l0" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    keys += ["linear.weight", "linear.bias"]
+    return keys
+
+
+class RlEngine:
+    """Read-level model (reference LatentSpaceLSTM.forward, latent_space_lstm.py:154-207)."""
+
+    def __init__(self, state, use_dwells=False, bidirectional=True, lstm_size=128, cnn_size=128,
+                 kernel_sizes=(1, 17), alphabet_size=6, embedding_size=6, normalise=True, device=0):
+        self._h = ctypes.c_void_p()
+        keys = rl_state_keys(bidirectional)
+        missing = [k for k in keys if k not in state]
+        if missing:
+            raise KeyError(f"state is missing {missing}")
+        arrs = [np.ascontiguousarray(np.asarray(state[k], dtype=np.float32)) for k in keys]
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        if len(kernel_sizes) != 2:
+            raise ValueError("the engine supports exactly two read-level conv layers")
+        desc = _lib.RlDesc(lstm_size, cnn_size, int(kernel_sizes[0]), int(kernel_sizes[1]), int(use_dwells),
+                           alphabet_size, embedding_size, int(bidirectional), 5, int(normalise))
+        _lib.check(_lib.load().mdk_rl_create(ctypes.byref(desc), ptrs, len(arrs), device,
+                                             ctypes.byref(self._h)), "mdk_rl_create")
+        self.use_dwells, self.device = use_dwells, device
+
+    def set_precision(self, half):
+        _lib.check(_lib.load().mdk_rl_set_precision(self._h, 1 if half else 0), "mdk_rl_set_precision")
+
+    def set_normalise(self, normalise):
+        _lib.check(_lib.load().mdk_rl_set_normalise(self._h, int(bool(normalise))), "mdk_rl_set_normalise")
+
+    def forward_host(self, x):
+        """x: (B, P, D, F) uint8 host array -> (B, P, 5) float32 host array."""
+        x = np.ascontiguousarray(x, dtype=np.uint8)
+        if x.ndim != 4:
+            raise ValueError(f"expected (B, P, D, F) input, got {x.shape}")
+        B, P, D, F = x.shape
+        out = np.empty((B, P, 5), dtype=np.float32)
+        _lib.check(_lib.load().mdk_rl_forward(self._h, x.ctypes.data, B, P, D, F, out.ctypes.data),
+                   "mdk_rl_forward")
+        return out
+
+    def forward_ptr(self, x_ptr, B, P, D, F, out_ptr, stream=None, host=False):
+        L = _lib.load()
+        if host:
+            _lib.check(L.mdk_rl_forward(self._h, x_ptr, B, P, D, F, out_ptr), "mdk_rl_forward")
+        else:
+            _lib.check(L.mdk_rl_forward_dev(self._h, x_ptr, B, P, D, F, out_ptr, stream), "mdk_rl_forward_dev")
+
+    def close(self):
+        if self._h:
+            _lib.load().mdk_rl_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def majority_forward_host(x, device=0):
     """MajorityVoteModel.forward on the device (reference majority_vote_model.py:37-53)."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -22,6 +22,12 @@ class GruDesc(ctypes.Structure):
                 ("num_classes", ctypes.c_int), ("normalise", ctypes.c_int)]
 
 
+class RlDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "lstm_size", "cnn_size", "kernel_size0", "kernel_size1", "use_dwells", "alphabet_size",
+        "embedding_size", "bidirectional", "num_classes", "normalise")]
+
+
 class GruTiming(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_float), ("gi_ms", ctypes.c_float * 4),
                 ("rec_ms", ctypes.c_float * 4), ("head_ms", ctypes.c_float),
@@ -44,6 +50,13 @@ ABI = {
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),
+    "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),
+    "mdk_rl_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mdk_rl_forward_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mdk_rl_set_precision": (_i, [_vp, _i]),
+    "mdk_rl_set_normalise": (_i, [_vp, _i]),
+    "mdk_rl_device": (_i, [_vp]),
+    "mdk_rl_destroy": (None, [_vp]),
     "mdk_majority_forward_dev": (_i, [_vp, _l, _vp, _i, _vp]),
     "mdk_majority_forward": (_i, [_vp, _l, _vp, _i]),
     "mdk_device_count": (_i, [ctypes.POINTER(_i)]),

@@ -214,7 +214,138 @@ class MajorityVoteModel(CountsMatrixModel):
         return self.forward(x).cpu()
 
 
-ARCHITECTURES = {"GRUModel": GRUModel, "MajorityVoteModel": MajorityVoteModel}
+class ReadLevelFeaturesModel(TorchModel):
+    """Models taking read level features (base_classes.py:28-34)."""
+
+    def get_model_input_features(self, batch):
+        """Return the read level features from the batch (base_classes.py:31-34)."""
+        return batch.read_level_features
+
+
+class _ReversibleLSTM(torch.nn.Module):
+    """Parameter container with the reference's naming (latent_space_lstm.py:11-33)."""
+
+    def __init__(self, *args, reverse=False, **kwargs):
+        super().__init__()
+        self.lstm = torch.nn.LSTM(*args, **kwargs)
+        self.reverse = reverse
+
+
+class _ReadLevelConv(torch.nn.Module):
+    """Parameter container mirroring read_level_modules.ReadLevelConv (:45-78)."""
+
+    def __init__(self, in_features, out_dim, kernel_sizes, channel_dim):
+        super().__init__()
+        layers, in_feat = [], in_features
+        for k in kernel_sizes:
+            assert k % 2 == 1, "kernel sizes must be odd (for equal & symmetric padding)"
+            layers += [torch.nn.Conv1d(in_feat, channel_dim, kernel_size=k, padding=(k - 1) // 2),
+                       torch.nn.ReLU(), torch.nn.BatchNorm1d(channel_dim)]
+            in_feat = channel_dim
+        self.convs = torch.nn.Sequential(*layers)
+        self.expansion_layer = torch.nn.Linear(channel_dim, out_dim)   # unused by the reference forward
+
+
+class LatentSpaceLSTM(ReadLevelFeaturesModel):
+    """Read-level model (latent_space_lstm.py:35-207) -- HIP engine behind the reference interface.
+
+    Same constructor, parameter names and `state_dict()` as the reference, so archives load
+    unchanged; `forward` is the fused read-level front end + MFMA LSTM stack of the engine.
+    Engine limits: lstm_size == cnn_size == 128, kernel_sizes == [1, 17], mean pooling.
+    """
+
+    def __init__(self, num_classes=5, lstm_size=128, cnn_size=128, kernel_sizes=[1, 17],
+                 pooler_type="mean", pooler_args={}, use_dwells=False, bases_alphabet_size=6,
+                 bases_embedding_size=6, bidirectional=True, time_steps=None):
+        super().__init__()
+        if time_steps is not None:
+            warnings.warn("timesteps is no lnoger required to be specified")
+        if pooler_type != "mean":
+            raise ValueError(f"Unknown PoolerType {pooler_type}")
+        self.num_classes = num_classes
+        self.lstm_size = lstm_size
+        self.cnn_size = cnn_size
+        self.kernel_sizes = kernel_sizes
+        self.pooler_type = pooler_type
+        self.pooler_args = pooler_args
+        self.use_dwells = use_dwells
+        self.bases_alphabet_size = bases_alphabet_size
+        self.bases_embedding_size = bases_embedding_size
+        self.base_embedder = torch.nn.Embedding(bases_alphabet_size, bases_embedding_size)
+        self.strand_embedder = torch.nn.Embedding(3, bases_embedding_size)
+        extra = 2 if use_dwells else 1
+        self.read_level_conv = _ReadLevelConv(bases_embedding_size + extra, lstm_size, kernel_sizes, cnn_size)
+        self.pre_pool_expansion_layer = torch.nn.Linear(cnn_size, lstm_size)
+        self.bidirectional = bidirectional
+        if bidirectional:
+            self.lstm = torch.nn.LSTM(lstm_size, lstm_size, num_layers=2, bidirectional=True, batch_first=True)
+        else:
+            self.lstm = torch.nn.Sequential(*[
+                _ReversibleLSTM(lstm_size, lstm_size, batch_first=True, reverse=not bool(i % 2))
+                for i in range(4)])
+        self.linear = torch.nn.Linear((1 + bidirectional) * lstm_size, self.num_classes)
+        self.normalise = True
+        self._engine = None
+        self._engine_key = None
+
+    def check_feature_encoder_compatibility(self, fenc):
+        """Check feature encoder is valid for this model (latent_space_lstm.py:209-240)."""
+        clsname = type(self).__name__
+        if "ReadAlignmentFeatureEncoder" not in {c.__name__ for c in type(fenc).__mro__}:
+            raise ValueError(f"{clsname} expects a ReadAlignmentFeatureEncoder.")
+        if len(getattr(fenc, "dtypes", ("",))) > 1:
+            raise NotImplementedError(f"{clsname} is currently only implemented for one dtype.")
+        if self.use_dwells and not getattr(fenc, "include_dwells", False):
+            raise ValueError("Model expects dwells, however include_dwells not set in the feature encoder.")
+
+    def engine(self):
+        dev_index = _hip_device_index(self.device())
+        key = (dev_index, tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters()),
+               tuple((b.data_ptr(), b._version) for b in self.buffers()))
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            state = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()
+                     if "num_batches_tracked" not in k}
+            self._engine = _engine.RlEngine(
+                state, use_dwells=self.use_dwells, bidirectional=self.bidirectional,
+                lstm_size=self.lstm_size, cnn_size=self.cnn_size, kernel_sizes=self.kernel_sizes,
+                alphabet_size=self.bases_alphabet_size, embedding_size=self.bases_embedding_size,
+                normalise=bool(self.normalise), device=dev_index)
+            self._engine_key = key
+        self._engine.set_precision(self.half_precision)
+        self._engine.set_normalise(bool(self.normalise))
+        return self._engine
+
+    def forward(self, x):
+        """x: uint8 (B, P, D, F) on the model's device -> (B, P, 5) float32 on the same device."""
+        eng = self.engine()
+        if x.device != self.device():
+            raise RuntimeError(f"input on {x.device}, model on {self.device()}")
+        if x.dim() != 4:
+            raise ValueError(f"expected (B, P, D, F) input, got {tuple(x.shape)}")
+        x = x.detach().to(torch.uint8).contiguous()
+        B, P, D, F = x.shape
+        out = torch.empty((B, P, 5), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        eng.forward_ptr(x.data_ptr(), B, P, D, F, out.data_ptr(), stream=stream)
+        return out
+
+    def _predict(self, x):
+        if x.device.type == "cpu":
+            eng = self.engine()
+            if x.dim() != 4:
+                raise ValueError(f"expected (B, P, D, F) input, got {tuple(x.shape)}")
+            x = x.detach().to(torch.uint8).contiguous()
+            B, P, D, F = x.shape
+            out = torch.empty((B, P, 5), dtype=torch.float32)
+            eng.forward_ptr(x.data_ptr(), B, P, D, F, out.data_ptr(), host=True)
+            return out
+        return self.forward(x).detach().cpu()
+
+
+ARCHITECTURES = {"GRUModel": GRUModel, "MajorityVoteModel": MajorityVoteModel,
+                 "LatentSpaceLSTM": LatentSpaceLSTM}
 
 
 def model_from_dict(model_dict):

@@ -262,3 +262,47 @@ def test_majority_vote_model(gold):
         assert np.abs(p - ref).max() <= 2e-7
     assert np.abs(engine.majority_forward_host(gold["gru_inputs"]["uniform"]) -
                   oracle.c_majority_forward(gold["gru_inputs"]["uniform"])).max() <= 2e-7
+
+
+# ---- read-level model (reference LatentSpaceLSTM) -------------------------------------------------
+import os  # noqa: E402
+from conftest import GOLD  # noqa: E402
+from oracle import rl_oracle  # noqa: E402
+
+RL_CONFIGS = {"bi": dict(), "uni": dict(bidirectional=False), "bi_dwells": dict(use_dwells=True)}
+
+
+@pytest.mark.parametrize("name", sorted(RL_CONFIGS))
+def test_read_level_model_goldens_from_unmodified_reference(name):
+    cases = np.load(os.path.join(GOLD, "rl_cases.npz"))
+    state = dict(np.load(os.path.join(GOLD, f"rl_weights_{name}.npz")))
+    e = engine.RlEngine(state, **RL_CONFIGS[name])
+    out = e.forward_host(cases[f"{name}/x"])
+    _check(out, cases[f"{name}/y"], what=f"read-level {name}")
+    e.close()
+
+
+@pytest.mark.parametrize("B,P,D", [(1, 1, 1), (2, 63, 3), (3, 65, 7), (9, 200, 12), (1, 700, 30)])
+def test_read_level_model_shapes_vs_oracle(B, P, D):
+    for name in ("bi", "uni"):
+        state = dict(np.load(os.path.join(GOLD, f"rl_weights_{name}.npz")))
+        x = rl_oracle.synth_reads(B, P, D, seed=7 * B + P + D)
+        ref = rl_oracle.rl_forward(x, state, **RL_CONFIGS[name])
+        e = engine.RlEngine(state, **RL_CONFIGS[name])
+        _check(e.forward_host(x), ref, what=f"read-level {name} B={B} P={P} D={D}")
+        e.close()
+
+
+def test_read_level_model_api(gold):
+    state = dict(np.load(os.path.join(GOLD, "rl_weights_bi.npz")))
+    m = models.LatentSpaceLSTM()
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+    assert all("num_batches_tracked" in k for k in missing.missing_keys)
+    m = m.to("cuda").eval()
+    x = rl_oracle.synth_reads(4, 150, 8, seed=3)
+    ref = rl_oracle.rl_forward(x, state)
+    p = m.predict_on_batch(Batch(read_level_features=torch.from_numpy(x)))
+    assert p.device.type == "cpu" and tuple(p.shape) == (4, 150, 5)
+    _check(p.numpy(), ref, what="LatentSpaceLSTM.predict_on_batch")
+    y = m(torch.from_numpy(x).cuda())
+    _check(y.cpu().numpy(), ref, what="LatentSpaceLSTM.forward")
