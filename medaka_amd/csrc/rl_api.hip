@@ -47,8 +47,7 @@ struct mdk_rl {
     std::vector<LstmLayer> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace
-    unsigned char *mask = nullptr;
-    int *nreads = nullptr;
+    int *mask = nullptr;
     size_t mask_cap = 0;
     float *gi = nullptr, *act[2] = {nullptr, nullptr};
     size_t ws_rows = 0;
@@ -64,7 +63,7 @@ extern "C" void mdk_rl_destroy(mdk_rl *m) {
     for (void *p : {(void *)m->base_emb, (void *)m->strand_emb, (void *)m->w1, (void *)m->b1, (void *)m->a1,
                     (void *)m->c1, (void *)m->w2frag, (void *)m->w3frag, (void *)m->b2, (void *)m->a2,
                     (void *)m->c2, (void *)m->b3, (void *)m->lin_w, (void *)m->lin_b, (void *)m->mask,
-                    (void *)m->nreads, (void *)m->gi, (void *)m->act[0], (void *)m->act[1], (void *)m->x_dev,
+                    (void *)m->gi, (void *)m->act[0], (void *)m->act[1], (void *)m->x_dev,
                     (void *)m->p_dev})
         free_dev(p);
     for (auto &L : m->layers) {
@@ -270,9 +269,8 @@ extern "C" int mdk_rl_device(const mdk_rl *m) { return m ? m->device : -1; }
 
 static int rl_workspace(mdk_rl *m, int B, int Dp, size_t rows) {
     if ((size_t)B * Dp > m->mask_cap) {
-        free_dev(m->mask); free_dev(m->nreads); m->mask = nullptr; m->nreads = nullptr; m->mask_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m->mask, (size_t)B * Dp));
-        HIP_TRY(hipMalloc((void **)&m->nreads, (size_t)B * sizeof(int)));
+        free_dev(m->mask); m->mask = nullptr; m->mask_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->mask, (size_t)B * Dp * sizeof(int)));
         m->mask_cap = (size_t)B * Dp;
     }
     if (rows > m->ws_rows) {
@@ -305,9 +303,10 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
 
     // ---- front end -> pooled (act[0], tile-major, one "direction")
     HIP_TRY(hipMemsetAsync(m->act[0], 0, rows * kH * sizeof(float), s));   // padding windows of the last tile
-    hipLaunchKernelGGL(k_rl_mask, dim3(B), dim3(256), 0, s, x_dev, P, Dp, F, m->mask, m->nreads);
+    HIP_TRY(hipMemsetAsync(m->mask, 0, (size_t)B * Dp * sizeof(int), s));
+    hipLaunchKernelGGL(k_rl_mask, dim3((P + 255) / 256, B), dim3(256), 0, s, x_dev, P, Dp, F, m->mask);
     RlFrontArgs fa;
-    fa.x = x_dev; fa.mask = m->mask; fa.nreads = m->nreads; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
+    fa.x = x_dev; fa.mask = m->mask; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
     fa.w1 = m->w1; fa.b1 = m->b1; fa.a1 = m->a1; fa.c1 = m->c1; fa.w2frag = m->w2frag; fa.b2 = m->b2; fa.a2 = m->a2;
     fa.c2 = m->c2; fa.w3frag = m->w3frag; fa.b3 = m->b3; fa.pooled = m->act[0];
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;

@@ -30,35 +30,45 @@ constexpr int kRlRowBytes = 272;                 // 128 channels x 2 B + 16 B pa
 constexpr int kRlTaps = 17;
 constexpr int kRlC = 128;                        // cnn_size == lstm_size == 128
 
-// mask[b][d] = any non-zero byte of read d in window b (latent_space_lstm.py:164-166);
-// nreads[b] = number of non-empty reads.  One work-group per window.
+// mask[b][d] = any non-zero byte of read d in window b (latent_space_lstm.py:164-166).
+// Work-group = (window, 256 positions); 16-byte loads; flags OR-ed into a zero-initialised
+// int array.  The number of non-empty reads is counted by the consumer (k_rl_front).
 static __global__ __launch_bounds__(256) void k_rl_mask(const unsigned char *__restrict__ x, int P, int Dp, int F,
-                                                 unsigned char *__restrict__ mask, int *__restrict__ nreads)
+                                                        int *__restrict__ mask)
 {
     __shared__ int flags[256];
-    const int b = blockIdx.x;
-    const unsigned char *xb = x + (size_t)b * P * Dp * F;
-    for (int d = threadIdx.x; d < 256; d += blockDim.x) flags[d] = 0;
+    const int b = blockIdx.y;
+    const size_t row_bytes = (size_t)Dp * F;
+    const size_t beg = (size_t)blockIdx.x * 256 * row_bytes;                       // within window b
+    const size_t end = min((size_t)P * row_bytes, beg + 256 * row_bytes);
+    const unsigned char *xb = x + (size_t)b * P * row_bytes;
+    flags[threadIdx.x] = 0;
     __syncthreads();
-    const size_t n = (size_t)P * Dp * F;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-        if (xb[i] != 0) {
-            const int d = (int)((i / F) % Dp);
-            flags[d] = 1;
+    // head / tail bytes around the 16-byte aligned body
+    const size_t addr0 = (size_t)(xb + beg);
+    size_t body_beg = beg + ((16 - (addr0 & 15)) & 15);
+    if (body_beg > end) body_beg = end;
+    const size_t body_end = body_beg + ((end - body_beg) & ~(size_t)15);
+    for (size_t i = beg + threadIdx.x; i < body_beg; i += 256)
+        if (xb[i]) flags[(i / F) % Dp] = 1;
+    for (size_t i = body_end + threadIdx.x; i < end; i += 256)
+        if (xb[i]) flags[(i / F) % Dp] = 1;
+    for (size_t i = body_beg + (size_t)threadIdx.x * 16; i < body_end; i += 256 * 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(xb + i);
+        if (v.x | v.y | v.z | v.w) {
+            const unsigned int wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if ((wds[k >> 2] >> (8 * (k & 3))) & 0xff) flags[((i + k) / F) % Dp] = 1;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int cnt = 0;
-        for (int d = 0; d < Dp; ++d) { mask[(size_t)b * Dp + d] = (unsigned char)flags[d]; cnt += flags[d]; }
-        nreads[b] = cnt;
-    }
+    if (threadIdx.x < Dp && flags[threadIdx.x]) atomicOr(&mask[(size_t)b * Dp + threadIdx.x], 1);
 }
 
 struct RlFrontArgs {
     const unsigned char *x;        // [B][P][Dp][F]
-    const unsigned char *mask;     // [B][Dp]
-    const int *nreads;             // [B]
+    const int *mask;               // [B][Dp]  0/1
     const float *base_emb;         // [A][6]
     const float *strand_emb;       // [3][6]
     const float *w1;               // [128][8]  conv1 weights, rows padded to 8 features
@@ -78,6 +88,7 @@ static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
     __shared__ float feat[kRlRows][8];
     __shared__ int fvalid[kRlRows];
     __shared__ float emb_b[8][6], emb_s[3][6];
+    __shared__ int n_reads_s;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,6 +98,11 @@ static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 
     if (tid < A.n_alpha * 6) emb_b[tid / 6][tid % 6] = A.base_emb[tid];
     if (tid >= 64 && tid < 64 + 18) emb_s[(tid - 64) / 6][(tid - 64) % 6] = A.strand_emb[tid - 64];
+    if (tid == 128) {
+        int cnt = 0;
+        for (int d = 0; d < A.Dp; ++d) cnt += A.mask[(size_t)b * A.Dp + d] != 0;
+        n_reads_s = cnt;
+    }
 
     // conv1 row of this thread's channel
     const int ci = tid & 127, rsel = tid >> 7;
@@ -236,7 +252,7 @@ static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
     }
 
     // ---- 4. mean over reads + bias, tile-major store (window b = tile b>>3, slot (b&7))
-    const float inv_n = 1.0f / (float)A.nreads[b];   // 0 reads -> inf/nan, as the reference's 0/0
+    const float inv_n = 1.0f / (float)n_reads_s;     // 0 reads -> inf/nan, as the reference's 0/0
     const int tile = b >> 3, wt = b & 7, gl = wt >> 1, ql = wt & 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {

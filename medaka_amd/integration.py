@@ -9,7 +9,8 @@ Reference flow (medaka/prediction.py:113-168):
 exactly as before; if the result is a `GRUModel` the engine supports AND the target device is
 a HIP device, an engine-backed `medaka_amd.models.GRUModel` with the same `state_dict()` is
 returned instead.  `medaka inference --cpu`, read-level models and unsupported shapes keep
-the reference implementation -- the engine itself never runs on the CPU.
+the reference implementation -- the engine itself never runs on the CPU.  `LatentSpaceLSTM`
+models with lstm_size = cnn_size = 128 are accelerated too (the bundled `rl_lstm384` is not).
 
 Opt in with `MEDAKA_AMD=1` in the environment of `medaka inference` or by
 calling `install()` before `medaka.prediction.predict(args)`.
@@ -31,7 +32,7 @@ def convert(model, device=None):
     dev = torch.device(device) if device is not None else model.device()
     if dev.type != "cuda":
         return model
-    if isinstance(model, (amd_models.GRUModel, amd_models.MajorityVoteModel)):
+    if isinstance(model, (amd_models.GRUModel, amd_models.MajorityVoteModel, amd_models.LatentSpaceLSTM)):
         return model
     if name == "GRUModel" and getattr(model, "gru_size", None) == 128:
         kwargs = model.to_dict()["kwargs"]
@@ -39,6 +40,16 @@ def convert(model, device=None):
         kwargs.pop("classify_activation", None)
         new = amd_models.GRUModel(**kwargs)
         new.load_state_dict(model.state_dict())
+        new.normalise = getattr(model, "normalise", True)
+        if getattr(model, "half_precision", False):
+            new.half()
+        return new.to(dev).eval()
+    if (name == "LatentSpaceLSTM" and getattr(model, "lstm_size", None) == 128
+            and getattr(model, "cnn_size", None) == 128 and list(getattr(model, "kernel_sizes", [])) == [1, 17]):
+        kwargs = model.to_dict()["kwargs"]
+        kwargs.pop("time_steps", None)
+        new = amd_models.LatentSpaceLSTM(**kwargs)
+        new.load_state_dict(model.state_dict(), strict=False)
         new.normalise = getattr(model, "normalise", True)
         if getattr(model, "half_precision", False):
             new.half()

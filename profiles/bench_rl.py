@@ -1,0 +1,52 @@
+"""Throughput of the read-level model (reference LatentSpaceLSTM, BASELINE config 4b) on one GPU.
+    python profiles/bench_rl.py [B P D] [--uni] [--half]
+Not the driver's bench (that is bench.py, the counts GRU); prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from medaka_amd import models  # noqa: E402
+from oracle import rl_oracle  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B, P, D = (int(a) for a in args[:3]) if len(args) >= 3 else (100, 10000, 50)
+uni = "--uni" in sys.argv
+name = "uni" if uni else "bi"
+state = dict(np.load(os.path.join(ROOT, "tests", "golden", f"rl_weights_{name}.npz")))
+m = models.LatentSpaceLSTM(bidirectional=not uni)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+m = m.to("cuda").eval()
+if "--half" in sys.argv:
+    m.half()
+x = torch.from_numpy(rl_oracle.synth_reads(min(B, 8), P, D, seed=1, empty_tail=False))
+x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous().cuda()
+with torch.inference_mode():
+    for _ in range(2):
+        y = m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 3
+    for _ in range(steps):
+        y = m(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+# conv2 dominates: 2 * 128 * 128 * 17 FLOP per (window, read, position)
+flop = 2.0 * 128 * 128 * 17 * B * P * D
+res = {"model": f"LatentSpaceLSTM({name}, lstm 128, cnn 128)", "B": B, "P": P, "D": D, "ms": dt * 1e3,
+       "positions_per_s": B * P / dt, "read_positions_per_s": B * P * D / dt,
+       "conv2_tflops_fp32_equiv": flop / dt / 1e12, "half": "--half" in sys.argv}
+# parity spot check on a small slice against the CPU oracle
+xs = x[:2, :300].contiguous()
+ref = rl_oracle.rl_forward(xs.cpu().numpy(), state, bidirectional=not uni)
+with torch.inference_mode():
+    out = m(xs).cpu().numpy()
+res["max_abs_dp_vs_oracle"] = float(np.abs(out - ref).max())
+print(json.dumps(res))

@@ -306,3 +306,33 @@ def test_read_level_model_api(gold):
     _check(p.numpy(), ref, what="LatentSpaceLSTM.predict_on_batch")
     y = m(torch.from_numpy(x).cuda())
     _check(y.cpu().numpy(), ref, what="LatentSpaceLSTM.forward")
+
+
+def test_read_level_model_half_precision():
+    state = dict(np.load(os.path.join(GOLD, "rl_weights_bi.npz")))
+    x = rl_oracle.synth_reads(5, 300, 10, seed=9)
+    ref = rl_oracle.rl_forward(x, state)
+    e = engine.RlEngine(state)
+    e.set_precision(True)      # fp16 LSTM stack; the read-level front end stays in split precision
+    out = e.forward_host(x)
+    e.close()
+    assert np.abs(out - ref).max() <= 2e-3
+    srt = np.sort(ref, -1)
+    clear = (srt[..., -1] - srt[..., -2]) > 4e-3
+    assert (out.argmax(-1) == ref.argmax(-1))[clear].all()
+
+
+def test_read_level_empty_reads_and_all_empty_window():
+    """Padded (all-zero) reads are excluded from the mean (read_level_modules.py:81-100); a window
+    with no read at all is 0/0 = NaN in the reference and here."""
+    state = dict(np.load(os.path.join(GOLD, "rl_weights_uni.npz")))
+    x = rl_oracle.synth_reads(3, 90, 6, seed=13, empty_tail=False)
+    x[0, :, 3:, :] = 0
+    x[2] = 0
+    ref = rl_oracle.rl_forward(x, state, bidirectional=False)
+    e = engine.RlEngine(state, bidirectional=False)
+    out = e.forward_host(x)
+    e.close()
+    _ok = ~np.isnan(ref)
+    assert np.isnan(out[2]).all() and np.isnan(ref[2]).all()
+    assert np.abs(out[:2] - ref[:2]).max() <= TOL
