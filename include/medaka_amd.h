@@ -108,6 +108,8 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 /* Tuning knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8      recurrence work-group granularity
  *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
+ *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
+ *                                                   larger batches run as equal passes
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
  *                             unless 0; 64 = per-phase cycle counters, see mdk_gru_debug_read) */
 int mdk_gru_set_option(mdk_gru *m, const char *key, int value);

@@ -57,6 +57,7 @@ struct mdk_gru {
     int variant = MDK_VARIANT_MFMA;
     int opt_tile_windows = 0;   // 0 auto, 4, 8
     int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
+    size_t max_rows_per_pass = 0;   // 0 = kMaxRowsPerPass
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
@@ -276,6 +277,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         if (value != 0 && value != 4 && value != 8 && value != 16)
             return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
         m->opt_tile_windows = value;
+    } else if (!strcmp(key, "max_rows_per_pass")) {
+        if (value < 0) return fail(MDK_ERR_ARG, "max_rows_per_pass must be >= 0 (0 = default)");
+        m->max_rows_per_pass = (size_t)value;
     } else if (!strcmp(key, "ablate")) {
         m->opt_ablate = value;
     } else if (!strcmp(key, "fuse_l0")) {
@@ -308,7 +312,9 @@ extern "C" int mdk_gru_device(const mdk_gru *m) { return m ? m->device : -1; }
 
 // ------------------------------------------------------------------------------------------
 // forward
-static const size_t kMaxRowsPerPass = (size_t)8 << 20;  // 8 Mi columns per pass: 24.6 GB gi + 16 GB act
+// Default column budget of one pass: 16 Mi columns = 51.5 GB gi + 2 x 17.2 GB activations, sized for
+// 288 GB of HBM (option "max_rows_per_pass" overrides it; tests use a tiny value).
+static const size_t kMaxRowsPerPass = (size_t)16 << 20;
 
 static int ensure_workspace(mdk_gru *m, size_t rows) {
     if (rows <= m->ws_rows) return MDK_OK;
@@ -542,9 +548,14 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;   // NULL = the legacy default stream, as for any HIP call
     // windows per pass, bounded so that the workspace stays within a fixed column budget
-    size_t per_pass = std::max<size_t>(1, kMaxRowsPerPass / (size_t)T);
-    per_pass = std::min<size_t>(per_pass, (size_t)B);
-    if (per_pass >= 8) per_pass -= per_pass % 8;   // full recurrence tiles
+    // and balanced: equal passes keep every launch's grid full (a 838 + 162 split of 1000 windows
+    // costs two full-length recurrences; 2 x 500 costs the same two, 1 x 1000 costs one)
+    const size_t budget = m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass;
+    const size_t fit = std::max<size_t>(1, budget / (size_t)T);
+    const size_t n_pass = ((size_t)B + fit - 1) / fit;
+    size_t per_pass = ((size_t)B + n_pass - 1) / n_pass;
+    if (n_pass > 1 && fit >= kTileWin)             // full recurrence tiles in all but the last pass
+        per_pass = std::min(fit - fit % kTileWin, (per_pass + kTileWin - 1) / kTileWin * kTileWin);
     int rc = ensure_workspace(m, ((per_pass + kTileWin - 1) / kTileWin * kTileWin) * (size_t)T);
     if (rc) return rc;
     EvTimer tm{m, s};

@@ -116,6 +116,19 @@ def test_both_tile_sizes_agree_bitwise(gold):
     _check(outs[1], oracle.c_gru_forward(x, weight_set(gold, "x3")), what="8-window tiles")
 
 
+def test_multi_pass_batches_agree_bitwise(gold):
+    """Batches above the workspace column budget run as equal passes (api.hip: mdk_gru_forward_dev);
+    windows are independent, so the result is the single-pass result bit for bit."""
+    x = synth.counts_windows(37, 300, seed=35)
+    e = engine.GruEngine(weight_set(gold, "x3"))
+    one = e.forward_host(x)
+    for budget in (300 * 16, 300 * 9, 300, 1):     # 3 passes of 16, 5 of 8, 37 of 1, 37 of 1
+        e.set_option("max_rows_per_pass", budget)
+        assert np.array_equal(e.forward_host(x), one), budget
+    e.close()
+    _check(one, oracle.c_gru_forward(x, weight_set(gold, "x3")), what="multi-pass")
+
+
 def test_fused_and_unfused_layer0_agree(gold):
     x = synth.counts_windows(9, 400, seed=41)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
