@@ -1,0 +1,324 @@
+// LSTM(384) of the bundled read-level models (`rl_lstm384`: LatentSpaceLSTM(lstm_size=384,
+// cnn_size=128, bidirectional=False), reference medaka/architectures/latent_space_lstm.py:129-149).
+//
+// One direction's recurrent matrix is 1536 x 384 = 2.4 MB as fp16 hi/lo fragments: it does not fit
+// the registers + LDS of one CU (0.67 MB), and re-streaming it from L2 every step would cost ~9 us
+// per step.  So the hidden units are split over a CLUSTER of 12 work-groups (= 12 CUs):
+//
+//   * member m owns units [32m, 32m+32) of all four gates = 128 gate columns; its wave w8 owns the
+//     16-column MFMA tile [i u0..3 | f u0..3 | g u0..3 | o u0..3], u = 32m + 4*w8 + 0..3, with the
+//     W_hh fragments of that tile resident in registers (12 k-steps x hi/lo = 96 VGPRs);
+//   * every step each member needs the WHOLE h_{t-1} (8 windows x 384 units).  Members publish their
+//     32 units as 8-byte {fp16 hi, fp16 lo, step tag} granules with one agent-scope relaxed atomic
+//     store each (= `global_store_dwordx2 sc1`, visible across CUs and XCDs without any fence),
+//     and gather all 3072 granules of the step with agent-scope atomic loads, re-polling a granule
+//     until its tag is the current step (MI355X_MICROARCH.md "Valid forms": 8-byte agent atomics on
+//     both sides; the data-tagged granule needs no separate flag).  Two parity buffers suffice:
+//     nobody can publish step t+2 before everybody has gathered step t (proof in DESIGN.md 4.5);
+//   * the gathered granules are written into the same LDS A-operand image the 128-unit kernel
+//     uses (rec_mfma.hpp), 12 k-steps long; rows = (window, hi|lo) as there;
+//   * the four gates of a unit sit in four lanes of one 16-lane row: activations are computed by
+//     all lanes (per-lane sigmoid/tanh constants), moved with three DPP row shifts, and lanes
+//     0..3 of each row finish the cell (c, h) for windows 2g+q.
+//
+// Cluster members must be co-resident (they spin on each other): the grid is 8 XCDs x 2 clusters
+// x 12 members = 192 work-groups <= 256 CUs, one per CU, launched on an otherwise idle device;
+// work-group b lands on XCD b % 8 (observed, used for speed only: a cluster shares one L2), and
+// every spin is bounded -- on time-out the kernel raises `status[0]` and exits instead of hanging.
+#pragma once
+#include "common.hpp"
+#include "rec_mfma.hpp"
+
+namespace mdk {
+
+constexpr int kWH = 384;                       // hidden units
+constexpr int kWG4 = 4 * kWH;                  // gate columns
+constexpr int kWC = 12;                        // work-groups (CUs) per cluster
+constexpr int kWKS = kWH / 32;                 // k-steps of the recurrent contraction
+constexpr int kWWin = 8;                       // windows per cluster (fp32-parity rows = 16)
+constexpr int kWImgBytes = kWKS * kHKStride;   // 13 056 B per A image
+constexpr int kWMaxClusters = 16;              // 2 per XCD
+constexpr int kWGranules = kWWin * kWH;        // per parity buffer
+constexpr int kWSpinLimit = 1 << 20;           // ~1-2 s of polling before giving up
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int PF>
+__global__ __launch_bounds__(512, 1) void k_lstm_wide(
+    const float *__restrict__ gi,       // [B*T][1536] permuted gate columns, bias folded, PRE-SCALED by S
+    const half8 *__restrict__ wfrag,    // [12 members][8 waves][12 ks][2 hi/lo][64]
+    float *__restrict__ out,            // [B*T][384]
+    unsigned long long *exch,           // [clusters][2 parity][8 windows][384 units] granules, zeroed
+    int *status,                        // [0] != 0: a cluster timed out
+    int B, int T, int reverse, float inv_scale, int n_clusters, int n_groups)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char img[2 * kWImgBytes];
+    __shared__ int s_abort[2];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int cluster = (idx / kWC) * 8 + xcd, member = idx % kWC;
+    if (cluster >= n_clusters) return;
+    const int c = lane & 15, g = lane >> 4, gate = c >> 2, u4 = c & 3;
+
+    half8 wf[kWKS][2];
+    {
+        const half8 *wp = wfrag + ((size_t)(member * 8 + w8) * (kWKS * 2)) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < kWKS; ++ks)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) wf[ks][sp] = wp[(size_t)(ks * 2 + sp) * 64];
+    }
+    constexpr float L2E = 1.44269504088896340736f;
+    // sigmoid(x) = rcp(1 + exp2(-x log2e));  tanh(x) = 1 - 2 rcp(1 + exp2(2x log2e)):  a*r + b
+    const float k_act = (gate == 2 ? 2.0f : -1.0f) * L2E * inv_scale;
+    const float a_act = gate == 2 ? -2.0f : 1.0f, b_act = gate == 2 ? 1.0f : 0.0f;
+    const int col = (member * 8 + w8) * 16 + c;      // permuted gi column of this lane
+    const int unit = 32 * member + 4 * w8 + u4;      // meaningful in the gate-0 lanes (c < 4)
+    unsigned long long *ex = exch + (size_t)cluster * (2 * kWGranules);
+    if (tid < 2) s_abort[tid] = 0;
+
+    // gather tasks: (window w, 4 consecutive units): 768 per step, threads 0..255 take two
+    int g_idx[2], g_off[2];
+    bool g_on[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = tid + 512 * j;
+        g_on[j] = id < kWWin * (kWH / 4);
+        const int w = (id / (kWH / 4)) & 7, k0 = 4 * (id % (kWH / 4));
+        g_idx[j] = w * kWH + k0;
+        g_off[j] = (k0 >> 5) * kHKStride + ((k0 >> 3) & 3) * kHGroupStride + (2 * w) * 16 + (k0 & 7) * 2;
+    }
+    const int rd_off = g * kHGroupStride + c * 16;
+    const long tstep = reverse ? -1 : 1;
+    const int t_first = reverse ? (T - 1) : 0;
+    const long gstride = tstep * (long)kWG4, ostride = tstep * (long)kWH;
+
+#pragma unroll
+    for (int ks = 0; ks < kWKS; ++ks)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][sp]));
+
+    unsigned int tag = 0;
+    for (int grp = cluster; grp < n_groups; grp += n_clusters) {
+        const float *gp[2];
+        float *op[2];
+        bool wok[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int win = grp * kWWin + 2 * g + q;
+            wok[q] = win < B;
+            if (!wok[q]) win = B - 1;
+            gp[q] = gi + ((size_t)win * T + t_first) * kWG4 + col;
+            op[q] = out + ((size_t)win * T + t_first) * kWH + unit;
+        }
+        float cst[2] = {0.f, 0.f};
+        __syncthreads();                                  // previous group's images are dead
+        {   // h_0 = 0: the image the first step reads
+            uint32_t *z = reinterpret_cast<uint32_t *>(img + (tag & 1) * kWImgBytes);
+            for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
+        }
+        float gq[PF][2];
+        auto refill = [&](int p, bool advance) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                gq[p][q] = gp[q][0];
+                if (advance) gp[q] += gstride;
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < PF; ++p) { gq[p][0] = 0.f; gq[p][1] = 0.f; }
+#pragma unroll
+        for (int p = 0; p + 1 < PF; ++p) refill(p, p + 1 < T);
+#pragma unroll
+        for (int p = 0; p + 1 < PF; ++p) { asm volatile("" ::"v"(gq[p][0])); asm volatile("" ::"v"(gq[p][1])); }
+        __syncthreads();
+
+        for (int step0 = 0; step0 < T; step0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int step = step0 + p;      // steps >= T run too (stores masked): all members agree
+                ++tag;
+                const unsigned char *rb = img + ((tag - 1) & 1) * kWImgBytes;
+                unsigned char *wb = img + (tag & 1) * kWImgBytes;
+                floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+                for (int ks = 0; ks < kWKS; ks += 2) {
+                    const half8 a0 = *reinterpret_cast<const half8 *>(rb + ks * kHKStride + rd_off);
+                    const half8 a1 = *reinterpret_cast<const half8 *>(rb + (ks + 1) * kHKStride + rd_off);
+                    acc0 = mfma16(a0, wf[ks][0], acc0);
+                    acc1 = mfma16(a1, wf[ks + 1][0], acc1);
+                    acc0 = mfma16(a0, wf[ks][1], acc0);
+                    acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+                }
+                refill((p + PF - 1) % PF, (step + PF) < T);
+                float act[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float pre = gq[p][q] + ((acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]));
+                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * k_act));
+                    act[q] = __builtin_fmaf(a_act, r, b_act);
+                }
+                unsigned long long *dst = ex + (size_t)(tag & 1) * kWGranules;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // lane c (< 4) holds i; f, g, o come from lanes c+4, c+8, c+12 of the same row
+                    const float fv = dpp_mov<0x104>(act[q]);     // row_shl:4
+                    const float gv = dpp_mov<0x108>(act[q]);     // row_shl:8
+                    const float ov = dpp_mov<0x10C>(act[q]);     // row_shl:12
+                    const float cv = __builtin_fmaf(fv, cst[q], act[q] * gv);
+                    cst[q] = cv;
+                    const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
+                    const float h = ov * tc;
+                    _Float16 hi, lo;
+                    split_f16(h * kActScale, hi, lo);
+                    if (c < 4) {
+                        const unsigned int payload = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                                                     ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+                        __hip_atomic_store(dst + (2 * g + q) * kWH + unit,
+                                           ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        if (step < T && wok[q]) op[q][0] = h;
+                    }
+                    op[q] += ostride;
+                }
+                // ---- gather the whole h_t of the cluster (own units included) into the next image
+                unsigned long long v[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v[j][i] = g_on[j] ? __hip_atomic_load(dst + g_idx[j] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : ((unsigned long long)tag << 32);
+                int spins = 0;
+                bool bad;
+                do {
+                    bad = false;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if ((unsigned int)(v[j][i] >> 32) != tag) {
+                                bad = true;
+                                v[j][i] = __hip_atomic_load(dst + g_idx[j] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                    if (bad) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kWSpinLimit) { s_abort[tag & 1] = 1; break; }
+                    }
+                } while (bad);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (g_on[j]) {
+                        const unsigned int p0 = (unsigned int)v[j][0], p1 = (unsigned int)v[j][1];
+                        const unsigned int p2 = (unsigned int)v[j][2], p3 = (unsigned int)v[j][3];
+                        uint2 hi4, lo4;
+                        hi4.x = (p0 & 0xffffu) | (p1 << 16);
+                        hi4.y = (p2 & 0xffffu) | (p3 << 16);
+                        lo4.x = (p0 >> 16) | (p1 & 0xffff0000u);
+                        lo4.y = (p2 >> 16) | (p3 & 0xffff0000u);
+                        *reinterpret_cast<uint2 *>(wb + g_off[j]) = hi4;
+                        *reinterpret_cast<uint2 *>(wb + g_off[j] + 16) = lo4;
+                    }
+                __syncthreads();
+                if (s_abort[tag & 1]) {
+                    if (tid == 0) atomicExch(status, 1);
+                    return;
+                }
+            }
+        }
+    }
+}
+
+// gi = (A W^T) * alpha + bias for the wide LSTM: A fp32 [M][32*KS] natural rows, W pre-packed
+// as fp16 hi/lo B-fragments in the PERMUTED column order k_lstm_wide reads ([96 tiles][KS][2][64]),
+// fp16x2 split with three products, fp32 accumulate.  Work-group = 64 rows (one contiguous run of
+// A) x all 1536 columns: A is converted once into LDS (hi and lo images, 16-byte fragments), the
+// 8 waves walk 12 column tiles each in chunks of 3 with B streaming from L2.
+constexpr int kWGemmRows = 64;
+constexpr int kWGemmBlk = kWGemmRows * 16 + 16;   // one (k-step, lane-group) block of an image + pad
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void k_gemm_rows(
+    const float *__restrict__ A, const half8 *__restrict__ wfrag, const float *__restrict__ bias,
+    float *__restrict__ out, long M, float a_scale, float alpha)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int K = 32 * KS;
+    constexpr int IMG = KS * 4 * kWGemmBlk;
+    unsigned char *ahi = lds, *alo = lds + IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * kWGemmRows;
+
+    for (int it = tid; it < kWGemmRows * 4 * KS; it += 512) {
+        const int row = it / (4 * KS), k8 = it % (4 * KS);
+        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+        if (row0 + row < M) {
+            const float4 *src = reinterpret_cast<const float4 *>(A + (size_t)(row0 + row) * K + k8 * 8);
+            x0 = src[0]; x1 = src[1];
+        }
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            _Float16 a, b;
+            split_f16(xv[i] * a_scale, a, b);
+            hi[i] = a; lo[i] = b;
+        }
+        *reinterpret_cast<half8 *>(ahi + k8 * kWGemmBlk + row * 16) = hi;
+        *reinterpret_cast<half8 *>(alo + k8 * kWGemmBlk + row * 16) = lo;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        const int nt0 = w8 * 12 + chunk * 3;
+        floatx4 acc[4][3];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[mt][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 bh[3], bl[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const half8 *wp = wfrag + (((size_t)(nt0 + j) * KS + ks) * 2) * 64 + lane;
+                bh[j] = wp[0];
+                bl[j] = wp[64];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int off = (ks * 4 + g) * kWGemmBlk + (mt * 16 + c) * 16;
+                const half8 ah = *reinterpret_cast<const half8 *>(ahi + off);
+                const half8 al = *reinterpret_cast<const half8 *>(alo + off);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[mt][j] = mfma16(ah, bh[j], acc[mt][j]);
+                    acc[mt][j] = mfma16(al, bh[j], acc[mt][j]);
+                    acc[mt][j] = mfma16(ah, bl[j], acc[mt][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int colj = (nt0 + j) * 16 + c;
+            const float bv = bias[colj];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = row0 + mt * 16 + 4 * g + r;
+                    if (row < M) out[(size_t)row * kWG4 + colj] = __builtin_fmaf(acc[mt][j][r], alpha, bv);
+                }
+        }
+    }
+}
+
+}  // namespace mdk

@@ -11,6 +11,7 @@
 #include "head.hpp"
 #include "host_common.hpp"
 #include "layout.hpp"
+#include "lstm_wide.hpp"
 #include "rec_mfma.hpp"
 #include "rl_front.hpp"
 
@@ -18,6 +19,9 @@ using namespace mdk;
 
 #ifndef MDK_PF
 #define MDK_PF 5
+#endif
+#ifndef MDK_WIDE_PF
+#define MDK_WIDE_PF 3
 #endif
 
 namespace {
@@ -28,6 +32,15 @@ struct LstmLayer {
     half8 *wih_frag = nullptr;   // [D][8][K/32][4][2][64]
     float *bias = nullptr;       // [D][512]  b_ih + b_hh
     float *inv_rec = nullptr, *up_rec = nullptr, *inv_gi = nullptr;   // [D]
+};
+
+// one uni-directional LSTM(384) layer of the wide model (lstm_wide.hpp)
+struct WideLayer {
+    int KS = kWKS, reverse = 0;
+    half8 *whh_frag = nullptr;   // [12][8][12][2][64]
+    half8 *wih_frag = nullptr;   // [96 tiles][KS][2][64]   permuted gate columns
+    float *bias = nullptr;       // [1536] permuted, multiplied by the recurrence scale
+    float inv_rec = 1.f, alpha = 1.f, a_scale = 1.f;
 };
 
 }  // namespace
@@ -44,6 +57,10 @@ struct mdk_rl {
     float s1 = 1.f, inv2 = 1.f, s2 = 1.f, inv3 = 1.f;
     int nf = 7;
     // recurrent stack + head
+    bool wide = false;           // lstm_size == 384: cluster recurrence (lstm_wide.hpp)
+    std::vector<WideLayer> wlayers;
+    unsigned long long *exch = nullptr;
+    int *status = nullptr;
     std::vector<LstmLayer> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace
@@ -70,6 +87,8 @@ extern "C" void mdk_rl_destroy(mdk_rl *m) {
         free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.bias);
         free_dev(L.inv_rec); free_dev(L.up_rec); free_dev(L.inv_gi);
     }
+    for (auto &L : m->wlayers) { free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.bias); }
+    free_dev(m->exch); free_dev(m->status);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -124,13 +143,64 @@ static int build_lstm_layer(LstmLayer &Ld, int K, int D, int reverse_mask, const
     return MDK_OK;
 }
 
+// Wide layer: w_ih is [1536][K] (K = 128 for the folded first layer, 384 after), w_hh [1536][384],
+// bias [1536] already summed.  Gate columns are permuted into the order k_lstm_wide's waves own:
+// tile nt = member * 8 + wave, column n of the tile = gate (n >> 2) of unit 32*member + 4*wave + (n & 3).
+static int build_wide_layer(WideLayer &Ld, int K, const float *w_ih, const float *w_hh, const float *bias,
+                            float a_scale, int reverse) {
+    Ld.KS = K / 32; Ld.reverse = reverse; Ld.a_scale = a_scale;
+    const float sw = pick_scale(w_hh, (size_t)kWG4 * kWH);
+    const float swi = pick_scale(w_ih, (size_t)kWG4 * K);
+    const float up_rec = kActScale * sw;
+    Ld.inv_rec = 1.0f / up_rec;
+    Ld.alpha = up_rec / (a_scale * swi);
+    std::vector<half8> whh((size_t)96 * kWKS * 2 * 64), wih((size_t)96 * Ld.KS * 2 * 64);
+    std::vector<float> bp(kWG4);
+    for (int nt = 0; nt < 96; ++nt) {
+        const int member = nt / 8, w8 = nt % 8;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = lane & 15, kg = lane >> 4;
+            const int j = (n >> 2) * kWH + 32 * member + 4 * w8 + (n & 3);
+            if (kg == 0) bp[nt * 16 + n] = bias[j] * up_rec;
+            for (int ks = 0; ks < kWKS; ++ks) {
+                half8 hi, lo;
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 a, b;
+                    split_host(w_hh[(size_t)j * kWH + 32 * ks + 8 * kg + i] * sw, a, b);
+                    hi[i] = a; lo[i] = b;
+                }
+                const size_t base = (((size_t)nt * kWKS + ks) * 2) * 64 + lane;
+                whh[base] = hi; whh[base + 64] = lo;
+            }
+            for (int ks = 0; ks < Ld.KS; ++ks) {
+                half8 hi, lo;
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 a, b;
+                    split_host(w_ih[(size_t)j * K + 32 * ks + 8 * kg + i] * swi, a, b);
+                    hi[i] = a; lo[i] = b;
+                }
+                const size_t base = (((size_t)nt * Ld.KS + ks) * 2) * 64 + lane;
+                wih[base] = hi; wih[base + 64] = lo;
+            }
+        }
+    }
+    int rc;
+    if ((rc = upload(&Ld.whh_frag, whh))) return rc;
+    if ((rc = upload(&Ld.wih_frag, wih))) return rc;
+    if ((rc = upload(&Ld.bias, bp))) return rc;
+    return MDK_OK;
+}
+
 extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int n_weights, int device,
                              mdk_rl **out) {
     if (!desc || !w || !out) return fail(MDK_ERR_ARG, "null argument");
     *out = nullptr;
-    if (desc->lstm_size != kH || desc->cnn_size != kRlC)
-        return fail(MDK_ERR_ARG, "unsupported lstm_size %d / cnn_size %d (engine supports 128 / 128)",
+    const bool wide = desc->lstm_size == kWH;
+    if ((desc->lstm_size != kH && !wide) || desc->cnn_size != kRlC)
+        return fail(MDK_ERR_ARG, "unsupported lstm_size %d / cnn_size %d (engine supports 128 or 384 / 128)",
                     desc->lstm_size, desc->cnn_size);
+    if (wide && desc->bidirectional)
+        return fail(MDK_ERR_ARG, "lstm_size 384 is supported as the 4 x uni-directional stack only (bidirectional=False)");
     if (desc->kernel_size0 != 1 || desc->kernel_size1 != kRlTaps)
         return fail(MDK_ERR_ARG, "unsupported kernel_sizes [%d, %d] (engine supports [1, 17])",
                     desc->kernel_size0, desc->kernel_size1);
@@ -148,6 +218,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
     mdk_rl *m = new mdk_rl();
     m->desc = *desc;
     m->device = device;
+    m->wide = wide;
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_rl_destroy(m); return code; };
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
@@ -163,7 +234,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
         for (int c = 0; c < 128; ++c)
             for (int f = 0; f < nf; ++f) w1[c * 8 + f] = w[2][(size_t)c * nf + f];
         std::vector<float> b1(w[3], w[3] + 128), a1(128), c1(128), b2(w[9], w[9] + 128), a2(128), c2(128),
-            b3(w[15], w[15] + 128);
+            b3(w[15], w[15] + 128);   // (wide model: the linear layer is folded into the LSTM, w3/b3 unused)
         for (int c = 0; c < 128; ++c) {
             a1[c] = w[4][c] / std::sqrt(w[7][c] + eps);
             c1[c] = w[5][c] - w[6][c] * a1[c];
@@ -193,7 +264,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
             y2max = std::max(y2max, std::max(std::fabs(c2[co]), std::fabs(a2[co] * bound + c2[co])));
         }
         m->s2 = pick_scale_max(y2max);
-        const float sw3 = pick_scale(w[14], (size_t)128 * 128);
+        const float sw3 = pick_scale(w[14], (size_t)desc->lstm_size * 128);
         m->inv3 = 1.0f / (m->s2 * sw3);
         // conv2 B-fragments [17][4 kb][4 waves][2 nt][2][64]: W2[co][ci][tau]
         std::vector<half8> w2f((size_t)kRlTaps * 4 * 4 * 2 * 2 * 64), w3f((size_t)4 * 4 * 2 * 2 * 64);
@@ -234,7 +305,42 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
             return bail(rc);
     }
     // ---- LSTM stack
-    if (desc->bidirectional) {
+    if (wide) {
+        // mean-pooling and Linear(128 -> 384) commute and no non-linearity separates the linear layer
+        // from the first LSTM projection: W' = W_ih0 W_pp, b' = W_ih0 b_pp + b_ih0 + b_hh0 (in double)
+        const float *w_pp = w[14], *b_pp = w[15];
+        std::vector<float> w0((size_t)kWG4 * 128), bias(kWG4);
+        {
+            std::vector<double> row(128);
+            for (int j = 0; j < kWG4; ++j) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bj = (double)w[18][j] + (double)w[19][j];
+                for (int k = 0; k < kWH; ++k) {
+                    const double a = w[16][(size_t)j * kWH + k];
+                    bj += a * b_pp[k];
+                    const float *wr = w_pp + (size_t)k * 128;
+                    for (int c = 0; c < 128; ++c) row[c] += a * wr[c];
+                }
+                for (int c = 0; c < 128; ++c) w0[(size_t)j * 128 + c] = (float)row[c];
+                bias[j] = (float)bj;
+            }
+        }
+        m->wlayers.resize(4);   // reverse - forward - reverse - forward (latent_space_lstm.py:141-149)
+        if ((rc = build_wide_layer(m->wlayers[0], 128, w0.data(), w[17], bias.data(), m->s2, 1))) return bail(rc);
+        for (int i = 1; i < 4; ++i) {
+            for (int j = 0; j < kWG4; ++j) bias[j] = w[16 + 4 * i + 2][j] + w[16 + 4 * i + 3][j];
+            if ((rc = build_wide_layer(m->wlayers[i], kWH, w[16 + 4 * i], w[16 + 4 * i + 1], bias.data(), kActScale,
+                                       (i % 2 == 0) ? 1 : 0)))
+                return bail(rc);
+        }
+        HIP_TRY(hipMalloc((void **)&m->exch, (size_t)kWMaxClusters * 2 * kWGranules * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&m->status, 64));
+        HIP_TRY(hipMemset(m->status, 0, 64));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<12>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 12 * 4 * kWGemmBlk));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * kWGemmBlk));
+    } else if (desc->bidirectional) {
         m->layers.resize(2);
         if ((rc = build_lstm_layer(m->layers[0], 128, 2, 2, w + 16))) return bail(rc);
         if ((rc = build_lstm_layer(m->layers[1], 256, 2, 2, w + 24))) return bail(rc);
@@ -245,7 +351,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
     }
     {
         const int Dl = desc->bidirectional ? 2 : 1;
-        std::vector<float> lw(w[32], w[32] + (size_t)5 * Dl * kH), lb(w[33], w[33] + 5);
+        std::vector<float> lw(w[32], w[32] + (size_t)5 * Dl * desc->lstm_size), lb(w[33], w[33] + 5);
         if ((rc = upload(&m->lin_w, lw)) || (rc = upload(&m->lin_b, lb))) return bail(rc);
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false, 4>),
@@ -284,6 +390,69 @@ static int rl_workspace(mdk_rl *m, int B, int Dp, size_t rows) {
     return MDK_OK;
 }
 
+// lstm_size = 384: front end (pool-only) -> 4 x [k_gemm_rows -> k_lstm_wide] -> head, natural layouts
+static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                           float *probs_dev, hipStream_t s) {
+    const size_t rows = (size_t)B * P;
+    if ((size_t)B * Dp > m->mask_cap) {
+        free_dev(m->mask); m->mask = nullptr; m->mask_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->mask, (size_t)B * Dp * sizeof(int)));
+        m->mask_cap = (size_t)B * Dp;
+    }
+    if (rows > m->ws_rows) {
+        free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
+        m->gi = m->act[0] = m->act[1] = nullptr; m->ws_rows = 0;
+        HIP_TRY(hipMalloc((void **)&m->gi, rows * kWG4 * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->act[0], rows * kWH * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->act[1], rows * kWH * sizeof(float)));
+        m->ws_rows = rows;
+    }
+    HIP_TRY(hipMemsetAsync(m->mask, 0, (size_t)B * Dp * sizeof(int), s));
+    hipLaunchKernelGGL(k_rl_mask, dim3((P + 255) / 256, B), dim3(256), 0, s, x_dev, P, Dp, F, m->mask);
+    RlFrontArgs fa;
+    fa.x = x_dev; fa.mask = m->mask; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
+    fa.w1 = m->w1; fa.b1 = m->b1; fa.a1 = m->a1; fa.c1 = m->c1; fa.w2frag = m->w2frag; fa.b2 = m->b2; fa.a2 = m->a2;
+    fa.c2 = m->c2; fa.w3frag = nullptr; fa.b3 = nullptr; fa.pooled = m->act[1];   // (B, P, 128) rows
+    fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
+    fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
+    hipLaunchKernelGGL(k_rl_front<false>, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+
+    const int n_groups = (B + kWWin - 1) / kWWin;
+    const int n_clusters = std::min(n_groups, kWMaxClusters);
+    const unsigned rec_grid = 8u * kWC * (unsigned)((n_clusters + 7) / 8);
+    const unsigned gemm_grid = (unsigned)((rows + kWGemmRows - 1) / kWGemmRows);
+    const float *in = m->act[1];
+    for (size_t l = 0; l < m->wlayers.size(); ++l) {
+        const WideLayer &Ld = m->wlayers[l];
+        float *outp = m->act[l & 1];
+        if (Ld.KS == 4)
+            hipLaunchKernelGGL(k_gemm_rows<4>, dim3(gemm_grid), dim3(512), (size_t)2 * 4 * 4 * kWGemmBlk, s, in,
+                               Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha);
+        else
+            hipLaunchKernelGGL(k_gemm_rows<12>, dim3(gemm_grid), dim3(512), (size_t)2 * 12 * 4 * kWGemmBlk, s, in,
+                               Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha);
+        HIP_TRY(hipMemsetAsync(m->exch, 0, (size_t)kWMaxClusters * 2 * kWGranules * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_lstm_wide<MDK_WIDE_PF>, dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, outp, m->exch,
+                           m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_groups);
+        in = outp;
+    }
+    {
+        const long blocks = std::min<long>(((long)rows + 15) / 16, 256 * 8);
+        hipLaunchKernelGGL(k_linear_softmax<6>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
+                           probs_dev, (long)rows, m->desc.normalise);
+    }
+    HIP_TRY(hipGetLastError());
+    // the cluster recurrence spins across work-groups with bounded waits: surface a time-out loudly
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, m->status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st != 0) {
+        HIP_TRY(hipMemsetAsync(m->status, 0, sizeof(int), s));
+        return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out (is another kernel occupying the GPU's CUs?)");
+    }
+    return MDK_OK;
+}
+
 extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
                                   float *probs_dev, void *stream) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
@@ -295,6 +464,7 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
     if (F < need_f) return fail(MDK_ERR_ARG, "expected >= %d features per read position, got %d", need_f, F);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
+    if (m->wide) return rl_forward_wide(m, x_dev, B, P, Dp, F, probs_dev, s);
     const int T = P, n_tiles = (B + kTileWin - 1) / kTileWin;
     const size_t rows = (size_t)n_tiles * kTileWin * T;
     int rc = rl_workspace(m, B, Dp, rows);
@@ -311,7 +481,7 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
     fa.c2 = m->c2; fa.w3frag = m->w3frag; fa.b3 = m->b3; fa.pooled = m->act[0];
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
     fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
-    hipLaunchKernelGGL(k_rl_front, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(k_rl_front<true>, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
 
     // ---- LSTM stack
     const int n_win = n_tiles * kTileWin;

@@ -77,12 +77,17 @@ struct RlFrontArgs {
     const float *b2, *a2, *c2;     // [128]
     const half8 *w3frag;           // [4 ks][4 waves][2 nt][2 hi/lo][64]
     const float *b3;               // [128]
-    float *pooled;                 // act_t layout, D = 1
+    float *pooled;                 // LIN: act_t layout, D = 1;  !LIN: natural [B][P][128]
     int B, P, Dp, F, nf, n_alpha;
     float s1, inv2, s2, inv3;      // operand scales (powers of two)
 };
 
-static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
+// LIN = true : Linear(128 -> 128) per read, pooled, + bias, tile-major store (lstm_size = 128);
+// LIN = false: the BN2 output itself is mean-pooled and stored as natural (B, P, 128) rows -- the
+//              linear layer commutes with the mean and is folded into the first LSTM projection
+//              by the host (rl_api.hip, wide model).
+template <bool LIN>
+__global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];   // 43.5 KB
     __shared__ float feat[kRlRows][8];
@@ -197,6 +202,20 @@ static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
             }
         }
         __syncthreads();   // everybody is done reading the conv1 tile
+        if constexpr (!LIN) {
+            // ---- 3'. bias + ReLU + BN2, pooled directly
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaf(acc[mt][nt][r], A.inv2, b2v[nt]);
+                        v = fmaxf(v, 0.f);
+                        pool[mt][nt][r] += fmaf(a2v[nt], v, c2v[nt]);
+                    }
+            continue;
+        }
         // ---- 3a. bias + ReLU + BN2, re-split as the A operand of the linear layer
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -251,8 +270,22 @@ static __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         __syncthreads();   // the tile is rewritten by the next read
     }
 
-    // ---- 4. mean over reads + bias, tile-major store (window b = tile b>>3, slot (b&7))
+    // ---- 4. mean over reads (+ bias), store
     const float inv_n = 1.0f / (float)n_reads_s;     // 0 reads -> inf/nan, as the reference's 0/0
+    if constexpr (!LIN) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = 32 * w + 16 * nt + n;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = p0 + 16 * mt + 4 * g + r;
+                    if (t < A.P) A.pooled[((size_t)b * A.P + t) * kRlC + co] = pool[mt][nt][r] * inv_n;
+                }
+        }
+        return;
+    }
     const int tile = b >> 3, wt = b & 7, gl = wt >> 1, ql = wt & 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {

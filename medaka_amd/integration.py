@@ -10,7 +10,8 @@ exactly as before; if the result is a `GRUModel` the engine supports AND the tar
 a HIP device, an engine-backed `medaka_amd.models.GRUModel` with the same `state_dict()` is
 returned instead.  `medaka inference --cpu`, read-level models and unsupported shapes keep
 the reference implementation -- the engine itself never runs on the CPU.  `LatentSpaceLSTM`
-models with lstm_size = cnn_size = 128 are accelerated too (the bundled `rl_lstm384` is not).
+models with cnn_size = 128 and lstm_size = 128, or lstm_size = 384 uni-directional (the bundled
+`rl_lstm384`), are accelerated too.
 
 Opt in with `MEDAKA_AMD=1` in the environment of `medaka inference` or by
 calling `install()` before `medaka.prediction.predict(args)`.
@@ -44,8 +45,10 @@ def convert(model, device=None):
         if getattr(model, "half_precision", False):
             new.half()
         return new.to(dev).eval()
-    if (name == "LatentSpaceLSTM" and getattr(model, "lstm_size", None) == 128
-            and getattr(model, "cnn_size", None) == 128 and list(getattr(model, "kernel_sizes", [])) == [1, 17]):
+    lstm_size = getattr(model, "lstm_size", None)
+    if (name == "LatentSpaceLSTM" and getattr(model, "cnn_size", None) == 128
+            and (lstm_size == 128 or (lstm_size == 384 and not getattr(model, "bidirectional", True)))
+            and list(getattr(model, "kernel_sizes", [])) == [1, 17]):
         kwargs = model.to_dict()["kwargs"]
         kwargs.pop("time_steps", None)
         new = amd_models.LatentSpaceLSTM(**kwargs)

@@ -251,7 +251,8 @@ class LatentSpaceLSTM(ReadLevelFeaturesModel):
 
     Same constructor, parameter names and `state_dict()` as the reference, so archives load
     unchanged; `forward` is the fused read-level front end + MFMA LSTM stack of the engine.
-    Engine limits: lstm_size == cnn_size == 128, kernel_sizes == [1, 17], mean pooling.
+    Engine limits: cnn_size == 128, kernel_sizes == [1, 17], mean pooling; lstm_size == 128, or
+    lstm_size == 384 with bidirectional=False (the bundled `rl_lstm384` models).
     """
 
     def __init__(self, num_classes=5, lstm_size=128, cnn_size=128, kernel_sizes=[1, 17],

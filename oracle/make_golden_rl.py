@@ -14,6 +14,10 @@ sys.path.insert(0, ROOT)
 from oracle import ref_shim, rl_oracle  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+WIDE_SEED = 21
+# name -> (windows, positions, padded depth, input seed): "two_groups" = one full + one ragged
+# 8-window group; "many_groups" = 17 groups > 16 clusters, so clusters loop over groups
+WIDE_CASES = {"two_groups": (11, 150, 7, 31), "many_groups": (130, 24, 3, 32)}
 
 
 def main():
@@ -41,6 +45,20 @@ def main():
         out[f"{name}/y"] = y
         print(name, y.shape, float(np.abs(rl_oracle.rl_forward(x, state, **{k: v for k, v in kw.items()}) - y).max()))
     np.savez_compressed(os.path.join(GOLD, "rl_cases.npz"), **out)
+
+    # rl_lstm384 architecture (BASELINE config 4b): weights regenerated from a seed by the tests
+    wide = {}
+    kw = dict(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False)
+    state = rl_oracle.synth_rl_state(seed=WIDE_SEED, **kw)
+    m = arch.LatentSpaceLSTM(**kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    for name, (B, P, D, seed) in WIDE_CASES.items():
+        x = rl_oracle.synth_reads(B, P, D, use_dwells=True, seed=seed)
+        y = m.predict_on_batch(te.Batch(read_level_features=torch.from_numpy(x))).numpy()
+        wide[f"{name}/x"] = x
+        wide[f"{name}/y"] = y
+        print("wide", name, y.shape, float(np.abs(rl_oracle.rl_forward(x, state, use_dwells=True, bidirectional=False) - y).max()))
+    np.savez_compressed(os.path.join(GOLD, "rl_wide_cases.npz"), **wide)
 
 
 if __name__ == "__main__":

@@ -32,3 +32,17 @@ def test_rl_oracle_against_live_reference():
     x = rl_oracle.synth_reads(2, 40, 5, seed=5)
     ref = m.predict_on_batch(te.Batch(read_level_features=torch.from_numpy(x))).numpy()
     assert np.abs(rl_oracle.rl_forward(x, state, bidirectional=False) - ref).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["two_groups", "many_groups"])
+def test_rl_oracle_matches_reference_goldens_lstm384(name):
+    """rl_lstm384 architecture (LSTM 384, 4 x uni-directional, dwells): weights regenerated from the
+    seed the golden script used, outputs from the unmodified reference."""
+    from oracle.make_golden_rl import WIDE_SEED
+    cases = np.load(os.path.join(GOLD, "rl_wide_cases.npz"))
+    state = rl_oracle.synth_rl_state(seed=WIDE_SEED, lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False)
+    out = rl_oracle.rl_forward(cases[f"{name}/x"], state, use_dwells=True, bidirectional=False)
+    ref = cases[f"{name}/y"]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-5
+    assert (out.argmax(-1) == ref.argmax(-1)).mean() >= 0.999

@@ -349,3 +349,61 @@ def test_read_level_empty_reads_and_all_empty_window():
     _ok = ~np.isnan(ref)
     assert np.isnan(out[2]).all() and np.isnan(ref[2]).all()
     assert np.abs(out[:2] - ref[:2]).max() <= TOL
+
+
+# ---- rl_lstm384 architecture: LSTM(384) recurrence spread over 12-CU clusters (lstm_wide.hpp) ----
+WIDE_KW = dict(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False)
+
+
+@pytest.fixture(scope="module")
+def wide_state():
+    from oracle.make_golden_rl import WIDE_SEED
+    return rl_oracle.synth_rl_state(seed=WIDE_SEED, **WIDE_KW)
+
+
+@pytest.mark.parametrize("name", ["two_groups", "many_groups"])
+def test_wide_read_level_goldens_from_unmodified_reference(name, wide_state):
+    cases = np.load(os.path.join(GOLD, "rl_wide_cases.npz"))
+    e = engine.RlEngine(wide_state, **WIDE_KW)
+    out = e.forward_host(cases[f"{name}/x"])
+    e.close()
+    _check(out, cases[f"{name}/y"], what=f"rl_lstm384 {name}")
+
+
+@pytest.mark.parametrize("B,P,D", [(1, 1, 1), (1, 33, 2), (8, 70, 4), (9, 129, 5), (17, 64, 3)])
+def test_wide_read_level_shapes_vs_oracle(B, P, D, wide_state):
+    x = rl_oracle.synth_reads(B, P, D, use_dwells=True, seed=5 * B + P + D)
+    ref = rl_oracle.rl_forward(x, wide_state, use_dwells=True, bidirectional=False)
+    e = engine.RlEngine(wide_state, **WIDE_KW)
+    out = e.forward_host(x)
+    _check(out, ref, what=f"rl_lstm384 B={B} P={P} D={D}")
+    # same engine again: exchange buffers / tags are reset per launch
+    assert np.array_equal(e.forward_host(x), out)
+    e.close()
+
+
+def test_wide_read_level_long_window_and_empty_window(wide_state):
+    """A 2000-position window (4 x 2000 cluster exchanges) next to an all-empty window (NaN, as the
+    reference's 0/0) in the same 8-window group: NaNs must stay in their own MFMA rows."""
+    x = rl_oracle.synth_reads(3, 2000, 4, use_dwells=True, seed=77, empty_tail=False)
+    x[1] = 0
+    ref = rl_oracle.rl_forward(x, wide_state, use_dwells=True, bidirectional=False)
+    e = engine.RlEngine(wide_state, **WIDE_KW)
+    out = e.forward_host(x)
+    e.close()
+    assert np.isnan(ref[1]).all() and np.isnan(out[1]).all()
+    _check(out[[0, 2]], ref[[0, 2]], what="rl_lstm384 long window")
+
+
+def test_wide_read_level_model_api_and_integration(wide_state):
+    m = models.LatentSpaceLSTM(**WIDE_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in wide_state.items()}, strict=False)
+    m = m.to("cuda").eval()
+    x = rl_oracle.synth_reads(5, 100, 6, use_dwells=True, seed=3)
+    ref = rl_oracle.rl_forward(x, wide_state, use_dwells=True, bidirectional=False)
+    p = m.predict_on_batch(Batch(read_level_features=torch.from_numpy(x)))
+    assert p.device.type == "cpu" and tuple(p.shape) == (5, 100, 5)
+    _check(p.numpy(), ref, what="LatentSpaceLSTM(384).predict_on_batch")
+    with pytest.raises(RuntimeError, match="bidirectional"):
+        engine.RlEngine(rl_oracle.synth_rl_state(seed=1, lstm_size=384, bidirectional=True, use_dwells=False),
+                        lstm_size=384, bidirectional=True)
