@@ -172,6 +172,13 @@ int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int 
                        void *stream);
 int mdk_rl_set_precision(mdk_rl *m, int precision);
 int mdk_rl_set_normalise(mdk_rl *m, int normalise);
+/* Tuning / test knobs (no reference counterpart):
+ *   "rec_windows_per_tile" = 0 (auto) | 4 | 8 | 16   lstm_size 128: recurrence work-group granularity
+ *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through
+ *                                                   granules, even when a cluster shares one XCD
+ *   "wide_groups_per_cluster" = 0 (auto) | 1 | 2     lstm_size 384: 8-window groups interleaved per cluster
+ *   "wide_poll_delay"      = 0..64 (default 7)      lstm_size 384, 1 group: 64-clock sleeps before the first poll */
+int mdk_rl_set_option(mdk_rl *m, const char *key, int value);
 int mdk_rl_device(const mdk_rl *m);
 void mdk_rl_destroy(mdk_rl *m);
 

@@ -17,6 +17,8 @@
 //     nobody can publish step t+2 before everybody has gathered step t (proof in DESIGN.md 4.5);
 //   * the gathered granules are written into the same LDS A-operand image the 128-unit kernel
 //     uses (rec_mfma.hpp), 12 k-steps long; rows = (window, hi|lo) as there;
+//   * two 8-window groups are interleaved per cluster so that one group's exchange latency is
+//     covered by the other group's MFMAs;
 //   * the four gates of a unit sit in four lanes of one 16-lane row: activations are computed by
 //     all lanes (per-lane sigmoid/tanh constants), moved with three DPP row shifts, and lanes
 //     0..3 of each row finish the cell (c, h) for windows 2g+q.
@@ -39,6 +41,7 @@ constexpr int kWWin = 8;                       // windows per cluster (fp32-pari
 constexpr int kWImgBytes = kWKS * kHKStride;   // 13 056 B per A image
 constexpr int kWMaxClusters = 16;              // 2 per XCD
 constexpr int kWGranules = kWWin * kWH;        // per parity buffer
+constexpr size_t kWExchWords = (size_t)kWMaxClusters * 4 * kWGranules + (size_t)kWMaxClusters * 16;   // 2 groups x 2 parities + XCD headers
 constexpr int kWSpinLimit = 1 << 20;           // ~1-2 s of polling before giving up
 
 template <int CTRL>
@@ -46,17 +49,27 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-template <int PF>
+// ABL: timing-only ablation mask (1 no gi loads, 2 accept the first poll, 4 no exchange at all,
+// 8 no h stores); results are garbage unless ABL == 0.
+//
+// Two window groups (A, B) of 8 windows are interleaved per cluster: while one group's published h
+// travels through L2, the other group's MFMAs and cell math run, so a gather normally finds its
+// granules on the first poll:
+//     [C_A(t) + G_B(t-1)]  barrier  [C_B(t) + G_A(t)]  barrier     (C = compute + publish, G = gather)
+// NGRP = 1: one group per cluster, the exchange latency is exposed every step -- used while the batch
+// has no more groups than clusters (then more clusters run in parallel instead).
+template <int PF, int NGRP, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const float *__restrict__ gi,       // [B*T][1536] permuted gate columns, bias folded, PRE-SCALED by S
     const half8 *__restrict__ wfrag,    // [12 members][8 waves][12 ks][2 hi/lo][64]
     float *__restrict__ out,            // [B*T][384]
-    unsigned long long *exch,           // [clusters][2 parity][8 windows][384 units] granules, zeroed
+    unsigned long long *exch,           // [clusters][2 groups][2 parity][8 windows][384 units] granules + headers, zeroed
     int *status,                        // [0] != 0: a cluster timed out
-    int B, int T, int reverse, float inv_scale, int n_clusters, int n_groups)
+    int B, int T, int reverse, float inv_scale, int n_clusters, int n_units, int force_wt, int poll_delay)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char img[2 * kWImgBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char img[2][2][kWImgBytes];   // [group][parity]
     __shared__ int s_abort[2];
+    __shared__ int s_same;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,19 +92,49 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const float a_act = gate == 2 ? -2.0f : 1.0f, b_act = gate == 2 ? 1.0f : 0.0f;
     const int col = (member * 8 + w8) * 16 + c;      // permuted gi column of this lane
     const int unit = 32 * member + 4 * w8 + u4;      // meaningful in the gate-0 lanes (c < 4)
-    unsigned long long *ex = exch + (size_t)cluster * (2 * kWGranules);
+    unsigned long long *ex = exch + (size_t)cluster * (4 * kWGranules);
     if (tid < 2) s_abort[tid] = 0;
 
-    // gather tasks: (window w, 4 consecutive units): 768 per step, threads 0..255 take two
-    int g_idx[2], g_off[2];
-    bool g_on[2];
+    // Do all 12 members share an XCD (= one L2)?  Then plain stores (kept in that L2) + L1-bypassing
+    // loads are coherent and several times faster than write-through granules that every reader must
+    // fetch from the fabric.  Placement is only OBSERVED to be block % 8, so the members tell each
+    // other their XCC_ID through the always-valid write-through protocol first and all take the same
+    // decision from the same 12 values.
+    {
+        unsigned long long *hdr = exch + (size_t)kWMaxClusters * (4 * kWGranules) + (size_t)cluster * 16;
+        const unsigned int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
+        if (tid == 0)
+            __hip_atomic_store(hdr + member, (0x7fffffffull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 64) {
+            unsigned long long x = 0;
+            int spins = 0;
+            bool ok;
+            do {
+                if (lane < kWC) x = __hip_atomic_load(hdr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = lane >= kWC || (unsigned int)(x >> 32) == 0x7fffffffu;
+                if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
+            } while (!__all(ok) && ++spins < kWSpinLimit);
+            const bool same = lane >= kWC || ((unsigned int)x & 0xf) == xcc;
+            if (lane == 0) s_same = (__all(ok) && __all(same)) ? 1 : (__all(ok) ? 0 : -1);
+        }
+        __syncthreads();
+        if (s_same < 0) {
+            if (tid == 0) atomicExch(status, 1);
+            return;
+        }
+    }
+    const bool same_xcd = s_same == 1 && !force_wt;
+
+    // gather: 1536 granule PAIRS (units u, u+1 of one window) per step; thread t takes pairs
+    // t, t+512, t+1024 with one 16-byte sc1 load each -- every load instruction of a wave covers
+    // 1 KB of contiguous memory -- and writes the fp16 hi pair / lo pair with two 4-byte LDS stores.
+    // (Each 8-byte half carries its own tag, so a torn 16-byte load is harmless.)
+    int g_off[3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int id = tid + 512 * j;
-        g_on[j] = id < kWWin * (kWH / 4);
-        const int w = (id / (kWH / 4)) & 7, k0 = 4 * (id % (kWH / 4));
-        g_idx[j] = w * kWH + k0;
-        g_off[j] = (k0 >> 5) * kHKStride + ((k0 >> 3) & 3) * kHGroupStride + (2 * w) * 16 + (k0 & 7) * 2;
+    for (int j = 0; j < 3; ++j) {
+        const int gidx = 2 * (tid + 512 * j);
+        const int w = gidx / kWH, u = gidx % kWH;
+        g_off[j] = (u >> 5) * kHKStride + ((u >> 3) & 3) * kHGroupStride + (2 * w) * 16 + (u & 7) * 2;
     }
     const int rd_off = g * kHGroupStride + c * 16;
     const long tstep = reverse ? -1 : 1;
@@ -104,132 +147,179 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
         for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][sp]));
 
     unsigned int tag = 0;
-    for (int grp = cluster; grp < n_groups; grp += n_clusters) {
-        const float *gp[2];
-        float *op[2];
-        bool wok[2];
+    for (int it = cluster; it < n_units; it += n_clusters) {   // unit = NGRP consecutive 8-window groups
+        const float *gp[2][2];
+        float *op[2][2];
+        bool wok[2][2];
+        float cst[2][2];
+        float gq[2][PF][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int win = grp * kWWin + 2 * g + q;
-            wok[q] = win < B;
-            if (!wok[q]) win = B - 1;
-            gp[q] = gi + ((size_t)win * T + t_first) * kWG4 + col;
-            op[q] = out + ((size_t)win * T + t_first) * kWH + unit;
-        }
-        float cst[2] = {0.f, 0.f};
-        __syncthreads();                                  // previous group's images are dead
-        {   // h_0 = 0: the image the first step reads
-            uint32_t *z = reinterpret_cast<uint32_t *>(img + (tag & 1) * kWImgBytes);
-            for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
-        }
-        float gq[PF][2];
-        auto refill = [&](int p, bool advance) {
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                gq[p][q] = gp[q][0];
-                if (advance) gp[q] += gstride;
+                int win = (NGRP * it + x) * kWWin + 2 * g + q;
+                wok[x][q] = win < B;
+                if (!wok[x][q]) win = B - 1;
+                gp[x][q] = gi + ((size_t)win * T + t_first) * kWG4 + col;
+                op[x][q] = out + ((size_t)win * T + t_first) * kWH + unit;
+                cst[x][q] = 0.f;
+            }
+        __syncthreads();                                  // previous pair's images are dead
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {   // h_0 = 0: the images the first step reads
+            uint32_t *z = reinterpret_cast<uint32_t *>(img[x][tag & 1]);
+            for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
+        }
+        auto refill = [&](int x, int p, bool advance) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if constexpr (ABL & 1) gq[x][p][q] = 0.f; else gq[x][p][q] = gp[x][q][0];
+                if (advance) gp[x][q] += gstride;
             }
         };
 #pragma unroll
-        for (int p = 0; p < PF; ++p) { gq[p][0] = 0.f; gq[p][1] = 0.f; }
+        for (int x = 0; x < 2; ++x) {
 #pragma unroll
-        for (int p = 0; p + 1 < PF; ++p) refill(p, p + 1 < T);
+            for (int p = 0; p < PF; ++p) { gq[x][p][0] = 0.f; gq[x][p][1] = 0.f; }
 #pragma unroll
-        for (int p = 0; p + 1 < PF; ++p) { asm volatile("" ::"v"(gq[p][0])); asm volatile("" ::"v"(gq[p][1])); }
+            for (int p = 0; p + 1 < PF; ++p) refill(x, p, p + 1 < T);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int p = 0; p + 1 < PF; ++p) { asm volatile("" ::"v"(gq[x][p][0])); asm volatile("" ::"v"(gq[x][p][1])); }
         __syncthreads();
+
+        // One half-step: compute + publish step `tag` of group x, and gather step `gtag` of the OTHER
+        // group (published one half-step ago) into its next image.  Vector-memory issue order is
+        // [gather loads] [gi refill] ... [publish + h stores] [wait gather]: the wait covers only the
+        // gather loads (vmcnt retires in order) whose data arrived under the MFMAs; the refill and the
+        // stores drain during the next half-step.  The barrier is LDS-only for the same reason.
+        auto gather_issue = [&](int y, unsigned int gtag, uint4 (&v)[3]) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ex + (size_t)(2 * y + (gtag & 1)) * kWGranules, 0,
+                                                                kWGranules * 8, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + 512 * j) * 16, 0, 16));
+        };
+        auto gather_finish = [&](int y, unsigned int gtag, uint4 (&v)[3]) {
+            unsigned char *wb = img[y][gtag & 1];
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ex + (size_t)(2 * y + (gtag & 1)) * kWGranules, 0,
+                                                                kWGranules * 8, 0x00020000);
+            int spins = 0;
+            bool bad;
+            do {
+                bad = false;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (!(ABL & 2) && (v[j].y != gtag || v[j].w != gtag)) {
+                        bad = true;
+                        v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + 512 * j) * 16, 0, 16));
+                    }
+                if (bad) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kWSpinLimit) { s_abort[tag & 1] = 1; break; }
+                }
+            } while (bad);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                *reinterpret_cast<unsigned int *>(wb + g_off[j]) = (v[j].x & 0xffffu) | (v[j].z << 16);
+                *reinterpret_cast<unsigned int *>(wb + g_off[j] + 16) = (v[j].x >> 16) | (v[j].z & 0xffff0000u);
+            }
+        };
+        auto half_step = [&](int x, int p, int step, bool do_gather, unsigned int gtag) {
+            const unsigned char *rb = img[x][(tag - 1) & 1];
+            // the other group published early in the previous half-step: its granules are in L2 by now
+            uint4 v[3];
+            if constexpr (NGRP == 2 && !(ABL & 4)) { if (do_gather) gather_issue(1 - x, gtag, v); }
+            // gi prefetch is issued AFTER the gather loads: vmcnt retires in order, so this half-step's
+            // gather wait does not include it and it has until the next half-step's to arrive
+            if constexpr (NGRP == 2) refill(x, (p + PF - 1) % PF, (step + PF) < T);    // the slot consumed one step ago
+            __builtin_amdgcn_sched_barrier(0);
+            floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int ks = 0; ks < kWKS; ks += 2) {
+                const half8 a0 = *reinterpret_cast<const half8 *>(rb + ks * kHKStride + rd_off);
+                const half8 a1 = *reinterpret_cast<const half8 *>(rb + (ks + 1) * kHKStride + rd_off);
+                acc0 = mfma16(a0, wf[ks][0], acc0);
+                acc1 = mfma16(a1, wf[ks + 1][0], acc1);
+                acc0 = mfma16(a0, wf[ks][1], acc0);
+                acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+            }
+            float act[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float pre = gq[x][p][q] + ((acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]));
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * k_act));
+                act[q] = __builtin_fmaf(a_act, r, b_act);
+            }
+            unsigned long long *dst = ex + (size_t)(2 * x + (tag & 1)) * kWGranules;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                // lane c (< 4) holds i; f, g, o come from lanes c+4, c+8, c+12 of the same row
+                const float fv = dpp_mov<0x104>(act[q]);     // row_shl:4
+                const float gv = dpp_mov<0x108>(act[q]);     // row_shl:8
+                const float ov = dpp_mov<0x10C>(act[q]);     // row_shl:12
+                const float cv = __builtin_fmaf(fv, cst[x][q], act[q] * gv);
+                cst[x][q] = cv;
+                const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
+                const float h = ov * tc;
+                _Float16 hi, lo;
+                split_f16(h * kActScale, hi, lo);
+                if (c < 4) {
+                    const unsigned int payload = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                                                 ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned long long gran = ((unsigned long long)tag << 32) | payload;
+                    if constexpr (!(ABL & 4)) {
+                        if (same_xcd)
+                            __hip_atomic_store(dst + (2 * g + q) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the shared L2
+                        else
+                            __hip_atomic_store(dst + (2 * g + q) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
+                    }
+                    if constexpr (!(ABL & 8)) { if (step < T && wok[x][q]) op[x][q][0] = h; }
+                }
+                op[x][q] += ostride;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NGRP == 1 && !(ABL & 4)) {
+                // own group, just published: a poll that misses costs a second L2 round trip, so give the
+                // other members' stores time to land first
+                for (int i = 0; i < poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+                gather_issue(x, gtag, v);
+            }
+            if constexpr (!(ABL & 4)) { if (do_gather) gather_finish(NGRP == 2 ? 1 - x : x, gtag, v); }
+            if constexpr (NGRP == 1) refill(x, (p + PF - 1) % PF, (step + PF) < T);
+            lds_barrier();
+        };
 
         for (int step0 = 0; step0 < T; step0 += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
                 const int step = step0 + p;      // steps >= T run too (stores masked): all members agree
                 ++tag;
-                const unsigned char *rb = img + ((tag - 1) & 1) * kWImgBytes;
-                unsigned char *wb = img + (tag & 1) * kWImgBytes;
-                floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-                for (int ks = 0; ks < kWKS; ks += 2) {
-                    const half8 a0 = *reinterpret_cast<const half8 *>(rb + ks * kHKStride + rd_off);
-                    const half8 a1 = *reinterpret_cast<const half8 *>(rb + (ks + 1) * kHKStride + rd_off);
-                    acc0 = mfma16(a0, wf[ks][0], acc0);
-                    acc1 = mfma16(a1, wf[ks + 1][0], acc1);
-                    acc0 = mfma16(a0, wf[ks][1], acc0);
-                    acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+                if constexpr (NGRP == 2) {
+                    half_step(0, p, step, step > 0, tag - 1);
+                    half_step(1, p, step, true, tag);
+                } else {
+                    half_step(0, p, step, true, tag);
                 }
-                refill((p + PF - 1) % PF, (step + PF) < T);
-                float act[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float pre = gq[p][q] + ((acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]));
-                    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * k_act));
-                    act[q] = __builtin_fmaf(a_act, r, b_act);
-                }
-                unsigned long long *dst = ex + (size_t)(tag & 1) * kWGranules;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    // lane c (< 4) holds i; f, g, o come from lanes c+4, c+8, c+12 of the same row
-                    const float fv = dpp_mov<0x104>(act[q]);     // row_shl:4
-                    const float gv = dpp_mov<0x108>(act[q]);     // row_shl:8
-                    const float ov = dpp_mov<0x10C>(act[q]);     // row_shl:12
-                    const float cv = __builtin_fmaf(fv, cst[q], act[q] * gv);
-                    cst[q] = cv;
-                    const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
-                    const float h = ov * tc;
-                    _Float16 hi, lo;
-                    split_f16(h * kActScale, hi, lo);
-                    if (c < 4) {
-                        const unsigned int payload = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
-                                                     ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
-                        __hip_atomic_store(dst + (2 * g + q) * kWH + unit,
-                                           ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        if (step < T && wok[q]) op[q][0] = h;
-                    }
-                    op[q] += ostride;
-                }
-                // ---- gather the whole h_t of the cluster (own units included) into the next image
-                unsigned long long v[2][4];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[j][i] = g_on[j] ? __hip_atomic_load(dst + g_idx[j] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                          : ((unsigned long long)tag << 32);
-                int spins = 0;
-                bool bad;
-                do {
-                    bad = false;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if ((unsigned int)(v[j][i] >> 32) != tag) {
-                                bad = true;
-                                v[j][i] = __hip_atomic_load(dst + g_idx[j] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                    if (bad) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > kWSpinLimit) { s_abort[tag & 1] = 1; break; }
-                    }
-                } while (bad);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (g_on[j]) {
-                        const unsigned int p0 = (unsigned int)v[j][0], p1 = (unsigned int)v[j][1];
-                        const unsigned int p2 = (unsigned int)v[j][2], p3 = (unsigned int)v[j][3];
-                        uint2 hi4, lo4;
-                        hi4.x = (p0 & 0xffffu) | (p1 << 16);
-                        hi4.y = (p2 & 0xffffu) | (p3 << 16);
-                        lo4.x = (p0 >> 16) | (p1 & 0xffff0000u);
-                        lo4.y = (p2 >> 16) | (p3 & 0xffff0000u);
-                        *reinterpret_cast<uint2 *>(wb + g_off[j]) = hi4;
-                        *reinterpret_cast<uint2 *>(wb + g_off[j] + 16) = lo4;
-                    }
-                __syncthreads();
                 if (s_abort[tag & 1]) {
                     if (tid == 0) atomicExch(status, 1);
                     return;
                 }
             }
+        }
+        if constexpr (NGRP == 2 && !(ABL & 4)) {   // B's last step: keeps "nobody publishes t+2 before everybody gathered t" across pairs
+            uint4 v[3];
+            gather_issue(1, tag, v);
+            gather_finish(1, tag, v);
+        }
+        __syncthreads();
+        if (s_abort[0] | s_abort[1]) {
+            if (tid == 0) atomicExch(status, 1);
+            return;
         }
     }
 }

@@ -50,6 +50,9 @@ struct mdk_rl {
     int device = 0;
     int precision = MDK_PREC_FP32;
     int opt_tile_windows = 0;
+    int opt_force_wt = 0;        // wide model: always use write-through granules (test hook)
+    int opt_wide_groups = 0;     // wide model: groups per cluster, 0 = auto
+    int opt_poll_delay = 7;      // wide model, one group per cluster: 64-clock sleeps before the first poll
     // front end
     float *base_emb = nullptr, *strand_emb = nullptr, *w1 = nullptr, *b1 = nullptr, *a1 = nullptr, *c1 = nullptr;
     half8 *w2frag = nullptr, *w3frag = nullptr;
@@ -333,7 +336,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
                                        (i % 2 == 0) ? 1 : 0)))
                 return bail(rc);
         }
-        HIP_TRY(hipMalloc((void **)&m->exch, (size_t)kWMaxClusters * 2 * kWGranules * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&m->exch, kWExchWords * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&m->status, 64));
         HIP_TRY(hipMemset(m->status, 0, 64));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<12>),
@@ -369,6 +372,25 @@ extern "C" int mdk_rl_set_precision(mdk_rl *m, int precision) {
 extern "C" int mdk_rl_set_normalise(mdk_rl *m, int normalise) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     m->desc.normalise = normalise ? 1 : 0;
+    return MDK_OK;
+}
+extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
+    if (!m || !key) return fail(MDK_ERR_ARG, "null argument");
+    if (!strcmp(key, "rec_windows_per_tile")) {
+        if (value != 0 && value != 4 && value != 8 && value != 16)
+            return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
+        m->opt_tile_windows = value;
+    } else if (!strcmp(key, "wide_write_through")) {
+        m->opt_force_wt = value ? 1 : 0;
+    } else if (!strcmp(key, "wide_poll_delay")) {
+        if (value < 0 || value > 64) return fail(MDK_ERR_ARG, "wide_poll_delay must be 0..64");
+        m->opt_poll_delay = value;
+    } else if (!strcmp(key, "wide_groups_per_cluster")) {
+        if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "wide_groups_per_cluster must be 0 (auto), 1 or 2");
+        m->opt_wide_groups = value;
+    } else {
+        return fail(MDK_ERR_ARG, "unknown option '%s'", key);
+    }
     return MDK_OK;
 }
 extern "C" int mdk_rl_device(const mdk_rl *m) { return m ? m->device : -1; }
@@ -417,8 +439,12 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
     hipLaunchKernelGGL(k_rl_front<false>, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
 
+    // up to 16 groups of 8 windows: one group per cluster; more: two interleaved groups per cluster
     const int n_groups = (B + kWWin - 1) / kWWin;
-    const int n_clusters = std::min(n_groups, kWMaxClusters);
+    int ngrp = n_groups > kWMaxClusters ? 2 : 1;
+    if (m->opt_wide_groups == 1 || m->opt_wide_groups == 2) ngrp = m->opt_wide_groups;
+    const int n_units = (n_groups + ngrp - 1) / ngrp;
+    const int n_clusters = std::min(n_units, kWMaxClusters);
     const unsigned rec_grid = 8u * kWC * (unsigned)((n_clusters + 7) / 8);
     const unsigned gemm_grid = (unsigned)((rows + kWGemmRows - 1) / kWGemmRows);
     const float *in = m->act[1];
@@ -431,9 +457,26 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
         else
             hipLaunchKernelGGL(k_gemm_rows<12>, dim3(gemm_grid), dim3(512), (size_t)2 * 12 * 4 * kWGemmBlk, s, in,
                                Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha);
-        HIP_TRY(hipMemsetAsync(m->exch, 0, (size_t)kWMaxClusters * 2 * kWGranules * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_lstm_wide<MDK_WIDE_PF>, dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, outp, m->exch,
-                           m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_groups);
+        HIP_TRY(hipMemsetAsync(m->exch, 0, kWExchWords * sizeof(unsigned long long), s));
+#define MDK_WIDE_N(NG, ABLV)                                                                             \
+    hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, ABLV>), dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, outp, \
+                       m->exch, m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_units, m->opt_force_wt, m->opt_poll_delay)
+#define MDK_WIDE(ABLV) do { if (ngrp == 2) MDK_WIDE_N(2, ABLV); else MDK_WIDE_N(1, ABLV); } while (0)
+#ifdef MDK_WIDE_ABLATE   // timing experiments only (profiles/): MDK_WIDE_ABL selects a garbage-result variant
+        switch (getenv("MDK_WIDE_ABL") ? atoi(getenv("MDK_WIDE_ABL")) : 0) {
+            case 1: MDK_WIDE(1); break;
+            case 2: MDK_WIDE(2); break;
+            case 3: MDK_WIDE(3); break;
+            case 4: MDK_WIDE(4); break;
+            case 5: MDK_WIDE(5); break;
+            case 13: MDK_WIDE(13); break;
+            default: MDK_WIDE(0);
+        }
+#else
+        MDK_WIDE(0);
+#endif
+#undef MDK_WIDE
+#undef MDK_WIDE_N
         in = outp;
     }
     {

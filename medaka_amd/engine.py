@@ -189,6 +189,9 @@ class RlEngine:
     def set_normalise(self, normalise):
         _lib.check(_lib.load().mdk_rl_set_normalise(self._h, int(bool(normalise))), "mdk_rl_set_normalise")
 
+    def set_option(self, key, value):
+        _lib.check(_lib.load().mdk_rl_set_option(self._h, key.encode(), int(value)), "mdk_rl_set_option")
+
     def forward_host(self, x):
         """x: (B, P, D, F) uint8 host array -> (B, P, 5) float32 host array."""
         x = np.ascontiguousarray(x, dtype=np.uint8)

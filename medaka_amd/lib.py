@@ -55,6 +55,7 @@ ABI = {
     "mdk_rl_forward_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mdk_rl_set_precision": (_i, [_vp, _i]),
     "mdk_rl_set_normalise": (_i, [_vp, _i]),
+    "mdk_rl_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "mdk_rl_device": (_i, [_vp]),
     "mdk_rl_destroy": (None, [_vp]),
     "mdk_majority_forward_dev": (_i, [_vp, _l, _vp, _i, _vp]),

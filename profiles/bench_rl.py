@@ -1,5 +1,5 @@
 """Throughput of the read-level model (reference LatentSpaceLSTM, BASELINE config 4b) on one GPU.
-    python profiles/bench_rl.py [B P D] [--uni] [--half]
+    python profiles/bench_rl.py [B P D] [--uni] [--half] [--wide]     (--wide = rl_lstm384 architecture)
 Not the driver's bench (that is bench.py, the counts GRU); prints one JSON line."""
 import json
 import os
@@ -18,15 +18,22 @@ from oracle import rl_oracle  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B, P, D = (int(a) for a in args[:3]) if len(args) >= 3 else (100, 10000, 50)
-uni = "--uni" in sys.argv
+wide = "--wide" in sys.argv
+uni = "--uni" in sys.argv or wide
 name = "uni" if uni else "bi"
-state = dict(np.load(os.path.join(ROOT, "tests", "golden", f"rl_weights_{name}.npz")))
-m = models.LatentSpaceLSTM(bidirectional=not uni)
+if wide:
+    kw = dict(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False)
+    state = rl_oracle.synth_rl_state(seed=21, **kw)
+    m = models.LatentSpaceLSTM(**kw)
+else:
+    kw = dict(bidirectional=not uni)
+    state = dict(np.load(os.path.join(ROOT, "tests", "golden", f"rl_weights_{name}.npz")))
+    m = models.LatentSpaceLSTM(**kw)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
 m = m.to("cuda").eval()
 if "--half" in sys.argv:
     m.half()
-x = torch.from_numpy(rl_oracle.synth_reads(min(B, 8), P, D, seed=1, empty_tail=False))
+x = torch.from_numpy(rl_oracle.synth_reads(min(B, 8), P, D, use_dwells=wide, seed=1, empty_tail=False))
 x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous().cuda()
 with torch.inference_mode():
     for _ in range(2):
@@ -40,12 +47,12 @@ with torch.inference_mode():
     dt = (time.perf_counter() - t0) / steps
 # conv2 dominates: 2 * 128 * 128 * 17 FLOP per (window, read, position)
 flop = 2.0 * 128 * 128 * 17 * B * P * D
-res = {"model": f"LatentSpaceLSTM({name}, lstm 128, cnn 128)", "B": B, "P": P, "D": D, "ms": dt * 1e3,
+res = {"model": f"LatentSpaceLSTM({name}, lstm {384 if wide else 128}, cnn 128)", "B": B, "P": P, "D": D, "ms": dt * 1e3,
        "positions_per_s": B * P / dt, "read_positions_per_s": B * P * D / dt,
        "conv2_tflops_fp32_equiv": flop / dt / 1e12, "half": "--half" in sys.argv}
 # parity spot check on a small slice against the CPU oracle
 xs = x[:2, :300].contiguous()
-ref = rl_oracle.rl_forward(xs.cpu().numpy(), state, bidirectional=not uni)
+ref = rl_oracle.rl_forward(xs.cpu().numpy(), state, use_dwells=wide, bidirectional=not uni)
 with torch.inference_mode():
     out = m(xs).cpu().numpy()
 res["max_abs_dp_vs_oracle"] = float(np.abs(out - ref).max())

@@ -379,6 +379,13 @@ def test_wide_read_level_shapes_vs_oracle(B, P, D, wide_state):
     _check(out, ref, what=f"rl_lstm384 B={B} P={P} D={D}")
     # same engine again: exchange buffers / tags are reset per launch
     assert np.array_equal(e.forward_host(x), out)
+    # both exchange protocols (shared-L2 plain stores / write-through granules) carry the same bits
+    e.set_option("wide_write_through", 1)
+    assert np.array_equal(e.forward_host(x), out)
+    # ... and so do one / two interleaved groups per cluster
+    for ngrp in (1, 2):
+        e.set_option("wide_groups_per_cluster", ngrp)
+        assert np.array_equal(e.forward_host(x), out)
     e.close()
 
 
