@@ -20,6 +20,7 @@
 #define MEDAKA_AMD_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -181,6 +182,27 @@ int mdk_rl_set_normalise(mdk_rl *m, int normalise);
 int mdk_rl_set_option(mdk_rl *m, const char *key, int value);
 int mdk_rl_device(const mdk_rl *m);
 void mdk_rl_destroy(mdk_rl *m);
+
+/* ---- PCIe diet either side of the network (opt-in fast paths) ----------
+ * f2: CountsFeatureEncoder(normalise='total') on the device -- reference medaka/features.py:907-911,
+ *     feature = (counts / np.maximum(1, depth)).astype(float32); bit-identical (float64 divide, then
+ *     float32 round, as numpy).  counts: (n_cols, n_features) uint16 raw pileup counts
+ *     (src/medaka_counts.c), depth: (n_cols) uint32, the depth of the parent major column
+ *     (features.py:884-885).  22-24 bytes per column cross PCIe instead of 40.
+ * f3: argmax decode on the device -- reference medaka/labels.py:1061-1065 (`np.argmax`, first maximum,
+ *     a NaN wins as in numpy) and the probability of that class (`np.take_along_axis`): 5 bytes per
+ *     column come back instead of 20.  Symbols / phred strings are then made on the host exactly as
+ *     labels.py:1066-1085 does. */
+int mdk_normalise_counts_dev(const uint16_t *counts_dev, const uint32_t *depth_dev, long n_cols, int n_features,
+                             float *x_dev, int device, void *stream);
+int mdk_decode_dev(const float *probs_dev, long n_cols, int n_classes, uint8_t *cls_dev, float *pmax_dev,
+                   int device, void *stream);
+/* Host entry: raw counts + depth in; any of probs (B,T,5) / cls (B,T) / pmax (B,T) out (NULL = not wanted,
+ * at least one must be given). */
+int mdk_gru_forward_counts(mdk_gru *m, const uint16_t *counts_host, const uint32_t *depth_host, int B, int T,
+                           float *probs_host, uint8_t *cls_host, float *pmax_host);
+/* As mdk_gru_forward but returning only the decoded classes (x: normalised fp32 features). */
+int mdk_gru_forward_decoded(mdk_gru *m, const float *x_host, int B, int T, uint8_t *cls_host, float *pmax_host);
 
 /* Raw device helpers for hosts that do not carry their own HIP runtime binding (bench, tests). */
 int mdk_device_count(int *count);

@@ -71,6 +71,8 @@ struct mdk_gru {
     // host-API staging
     float *x_dev = nullptr, *p_dev = nullptr;
     size_t x_cap = 0, p_cap = 0;
+    unsigned char *aux_dev = nullptr;   // raw counts + depth in, decoded classes + probabilities out
+    size_t aux_cap = 0;
     hipStream_t stream = nullptr;
     // timing
     bool timing = false;
@@ -87,7 +89,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
         free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.wx_frag); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
-    free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
+    free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -605,6 +607,101 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     }
     return MDK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// f2 / f3: device-side normalisation of raw counts and argmax decode (PCIe diet)
+extern "C" int mdk_normalise_counts_dev(const uint16_t *counts_dev, const uint32_t *depth_dev, long n_cols,
+                                        int n_features, float *x_dev, int device, void *stream) {
+    if (n_cols < 0 || n_features < 1) return fail(MDK_ERR_ARG, "bad shape n_cols=%ld n_features=%d", n_cols, n_features);
+    if (n_cols == 0) return MDK_OK;
+    if (!counts_dev || !depth_dev || !x_dev) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(device));
+    const long n = n_cols * n_features;
+    hipLaunchKernelGGL(k_normalise_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       counts_dev, depth_dev, x_dev, n_cols, n_features);
+    HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+extern "C" int mdk_decode_dev(const float *probs_dev, long n_cols, int n_classes, uint8_t *cls_dev, float *pmax_dev,
+                              int device, void *stream) {
+    if (n_cols < 0 || n_classes < 1 || n_classes > 255) return fail(MDK_ERR_ARG, "bad shape n_cols=%ld n_classes=%d", n_cols, n_classes);
+    if (n_cols == 0) return MDK_OK;
+    if (!probs_dev || !cls_dev || !pmax_dev) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs_dev,
+                       cls_dev, pmax_dev, n_cols, n_classes);
+    HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+// shared body of the two host entries: exactly one of x_host / counts_host is given
+static int forward_any(mdk_gru *m, const float *x_host, const uint16_t *counts_host, const uint32_t *depth_host, int B,
+                       int T, float *probs_host, uint8_t *cls_host, float *pmax_host) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
+    if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); return MDK_OK; }
+    if (!x_host && !(counts_host && depth_host)) return fail(MDK_ERR_ARG, "null input buffer");
+    if (!probs_host && !(cls_host && pmax_host)) return fail(MDK_ERR_ARG, "no output requested (probs, or cls + pmax)");
+    if ((cls_host == nullptr) != (pmax_host == nullptr)) return fail(MDK_ERR_ARG, "cls and pmax go together");
+    HIP_TRY(hipSetDevice(m->device));
+    const int F = m->desc.num_features, C = m->desc.num_classes;
+    const size_t cols = (size_t)B * T, nx = cols * F, np = cols * C;
+    if (nx > m->x_cap) {
+        free_dev(m->x_dev); m->x_dev = nullptr; m->x_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->x_dev, nx * sizeof(float)));
+        m->x_cap = nx;
+    }
+    if (np > m->p_cap) {
+        free_dev(m->p_dev); m->p_dev = nullptr; m->p_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->p_dev, np * sizeof(float)));
+        m->p_cap = np;
+    }
+    // aux: [depth u32 | pmax f32 (cols)] [counts u16 (cols*F)] [cls u8 (cols)], 16-byte aligned pieces
+    const size_t off_counts = (cols * 4 + 15) / 16 * 16, off_cls = off_counts + (cols * F * 2 + 15) / 16 * 16;
+    const size_t aux_need = off_cls + cols;
+    if (aux_need > m->aux_cap) {
+        free_dev(m->aux_dev); m->aux_dev = nullptr; m->aux_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->aux_dev, aux_need));
+        m->aux_cap = aux_need;
+    }
+    hipStream_t s = m->stream;
+    if (counts_host) {
+        uint32_t *dd = reinterpret_cast<uint32_t *>(m->aux_dev);
+        uint16_t *cd = reinterpret_cast<uint16_t *>(m->aux_dev + off_counts);
+        HIP_TRY(hipMemcpyAsync(dd, depth_host, cols * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(cd, counts_host, cols * F * 2, hipMemcpyHostToDevice, s));
+        int rc = mdk_normalise_counts_dev(cd, dd, (long)cols, F, m->x_dev, m->device, s);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(m->x_dev, x_host, nx * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    int rc = mdk_gru_forward_dev(m, m->x_dev, B, T, m->p_dev, s);
+    if (rc) return rc;
+    if (probs_host) HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (cls_host) {
+        float *pm = reinterpret_cast<float *>(m->aux_dev);          // depth is dead by now
+        uint8_t *cl = m->aux_dev + off_cls;
+        rc = mdk_decode_dev(m->p_dev, (long)cols, C, cl, pm, m->device, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(cls_host, cl, cols, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(pmax_host, pm, cols * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_forward_counts(mdk_gru *m, const uint16_t *counts_host, const uint32_t *depth_host, int B,
+                                      int T, float *probs_host, uint8_t *cls_host, float *pmax_host) {
+    if (m && B > 0 && T > 0 && !(counts_host && depth_host)) return fail(MDK_ERR_ARG, "null input buffer");
+    return forward_any(m, nullptr, counts_host, depth_host, B, T, probs_host, cls_host, pmax_host);
+}
+
+extern "C" int mdk_gru_forward_decoded(mdk_gru *m, const float *x_host, int B, int T, uint8_t *cls_host,
+                                       float *pmax_host) {
+    if (m && B > 0 && T > 0 && !x_host) return fail(MDK_ERR_ARG, "null input buffer");
+    return forward_any(m, x_host, nullptr, nullptr, B, T, nullptr, cls_host, pmax_host);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -172,4 +172,36 @@ static __global__ __launch_bounds__(256) void k_majority(const float *__restrict
     for (int c = 0; c < 5; ++c) probs[i * 5 + c] = p[c];
 }
 
+// CountsFeatureEncoder(normalise='total') on the device (reference medaka/features.py:907-911):
+//     feature = (counts / np.maximum(1, depth)).astype(float32)
+// numpy divides the integer arrays in float64 and then rounds to float32; the same two IEEE
+// roundings are done here (v_div f64, v_cvt_f32_f64), so the result is bit-identical.
+static __global__ __launch_bounds__(256) void k_normalise_counts(const unsigned short *__restrict__ counts,
+                                                                 const unsigned int *__restrict__ depth,
+                                                                 float *__restrict__ x, long n_cols, int F)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cols * F) return;
+    const unsigned int d = depth[i / F];
+    x[i] = (float)((double)counts[i] / (double)(d > 1u ? d : 1u));
+}
+
+// argmax decode (reference medaka/labels.py:1061-1065): most probable class -- the FIRST maximum,
+// as numpy.argmax -- and its probability; 5 bytes per column leave the device instead of 20.
+static __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ probs, unsigned char *__restrict__ cls,
+                                                       float *__restrict__ pmax, long n_cols, int C)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cols) return;
+    const float *r = probs + i * C;
+    int best = 0;
+    float bv = r[0];
+    for (int c = 1; c < C; ++c) {
+        const float v = r[c];
+        if (bv == bv && (v > bv || v != v)) { bv = v; best = c; }   // numpy.argmax: the first NaN wins
+    }
+    cls[i] = (unsigned char)best;
+    pmax[i] = bv;
+}
+
 }  // namespace mdk

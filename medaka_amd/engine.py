@@ -124,6 +124,36 @@ class GruEngine:
                    "mdk_gru_forward")
         return out
 
+    def forward_counts_host(self, counts, depth, probs=True, decoded=False):
+        """Raw pileup counts (B,T,F) uint16 + per-column depth (B,T) uint32 -> probabilities and/or
+        (argmax class uint8, its probability float32): normalisation (features.py:907-911) and
+        argmax decode (labels.py:1061-1065) run on the device."""
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        depth = np.ascontiguousarray(depth, dtype=np.uint32)
+        if counts.ndim != 3 or counts.shape[2] != self.num_features or depth.shape != counts.shape[:2]:
+            raise ValueError(f"expected counts (B, T, {self.num_features}) and depth (B, T), got {counts.shape}, {depth.shape}")
+        if not (probs or decoded):
+            raise ValueError("nothing requested")
+        B, T, _ = counts.shape
+        p = np.empty((B, T, self.num_classes), dtype=np.float32) if probs else None
+        cls = np.empty((B, T), dtype=np.uint8) if decoded else None
+        pmax = np.empty((B, T), dtype=np.float32) if decoded else None
+        _lib.check(_lib.load().mdk_gru_forward_counts(
+            self._h, counts.ctypes.data, depth.ctypes.data, B, T, p.ctypes.data if probs else None,
+            cls.ctypes.data if decoded else None, pmax.ctypes.data if decoded else None), "mdk_gru_forward_counts")
+        return tuple(a for a in (p, cls, pmax) if a is not None) if decoded else p
+
+    def forward_decoded_host(self, x):
+        """x: (B,T,F) float32 -> (argmax class (B,T) uint8, its probability (B,T) float32)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[2] != self.num_features:
+            raise ValueError(f"expected (B, T, {self.num_features}) input, got {x.shape}")
+        B, T, _ = x.shape
+        cls, pmax = np.empty((B, T), dtype=np.uint8), np.empty((B, T), dtype=np.float32)
+        _lib.check(_lib.load().mdk_gru_forward_decoded(self._h, x.ctypes.data, B, T, cls.ctypes.data,
+                                                       pmax.ctypes.data), "mdk_gru_forward_decoded")
+        return cls, pmax
+
     def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
         """Raw-pointer forward: host pointers (`host=True`) or device pointers + hipStream_t."""
         L = _lib.load()
@@ -239,3 +269,18 @@ def selftest_mfma(device=0):
     _lib.check(_lib.load().mdk_selftest_mfma(device, ctypes.byref(err), ctypes.byref(sub)),
                "mdk_selftest_mfma")
     return err.value, bool(sub.value)
+
+
+def decode_consensus(cls, pmax=None, symbols="*ACGT", with_gaps=False, with_qualities=False, cap=70.0):
+    """Host half of the on-device decode: the reference's `HaploidLabelScheme.decode_consensus`
+    (medaka/labels.py:1053-1085) continued from the device's (argmax, max-probability) pair of ONE
+    sample -- gap removal, symbol lookup, and the phred string of `_phred` (labels.py:388-402)."""
+    mp = np.asarray(cls).astype(np.int64)
+    gap = symbols.index("*")
+    mask = np.ones(mp.shape, dtype=bool) if with_gaps else (mp != gap)
+    seq = np.array([ord(ch) for ch in symbols], dtype="u1")[mp[mask]].tobytes().decode()
+    if not with_qualities:
+        return seq
+    err = np.clip(1 - np.asarray(pmax)[mask], 10 ** (-cap / 10.0), 1)
+    q = np.minimum(-10 * np.log10(err), cap)
+    return seq, (q.astype("u1") + 33).tobytes().decode()

@@ -58,6 +58,10 @@ ABI = {
     "mdk_rl_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "mdk_rl_device": (_i, [_vp]),
     "mdk_rl_destroy": (None, [_vp]),
+    "mdk_normalise_counts_dev": (_i, [_vp, _vp, _l, _i, _vp, _i, _vp]),
+    "mdk_decode_dev": (_i, [_vp, _l, _i, _vp, _vp, _i, _vp]),
+    "mdk_gru_forward_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "mdk_gru_forward_decoded": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mdk_majority_forward_dev": (_i, [_vp, _l, _vp, _i, _vp]),
     "mdk_majority_forward": (_i, [_vp, _l, _vp, _i]),
     "mdk_device_count": (_i, [ctypes.POINTER(_i)]),

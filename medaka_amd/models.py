@@ -19,6 +19,7 @@ import inspect
 import logging
 import warnings
 
+import numpy as np
 import torch
 
 from medaka_amd import engine as _engine
@@ -182,6 +183,23 @@ class GRUModel(CountsMatrixModel):
             eng.forward_ptr(x.data_ptr(), B, T, out.data_ptr(), host=True)
             return out
         return self.forward(x).detach().cpu()
+
+    # -- opt-in fast paths around the network (no reference counterpart) ----
+    def predict_on_counts(self, counts, depth, decoded=False):
+        """Raw pileup counts (B,T,10) uint16 + depth of the parent major column (B,T) uint32, host
+        arrays/tensors, in place of `CountsFeatureEncoder(normalise='total')` features
+        (features.py:907-911): 24 instead of 40 bytes per column cross PCIe.  Returns the (B,T,5)
+        float32 probabilities as `predict_on_batch` does, or with `decoded` the pair (argmax class
+        uint8 (B,T), its probability float32 (B,T)) that `decode_consensus` (labels.py:1061-1065)
+        starts from -- 5 bytes per column back instead of 20 (see engine.decode_consensus)."""
+        counts = np.asarray(counts.numpy() if isinstance(counts, torch.Tensor) else counts)
+        depth = np.asarray(depth.numpy() if isinstance(depth, torch.Tensor) else depth)
+        with torch.inference_mode():
+            eng = self.engine()
+        if decoded:
+            cls, pmax = eng.forward_counts_host(counts, depth, probs=False, decoded=True)
+            return torch.from_numpy(cls), torch.from_numpy(pmax)
+        return torch.from_numpy(eng.forward_counts_host(counts, depth))
 
 
 class MajorityVoteModel(CountsMatrixModel):

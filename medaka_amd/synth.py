@@ -22,15 +22,21 @@ NUM_CLASSES = 5
 
 def counts_windows(n_windows, n_cols, depth=60, seed=1234, p_sub=0.01,
                    p_del=0.01, p_ins=0.01, p_draft_err=0.02,
-                   return_labels=False):
+                   return_labels=False, raw=False):
     """Draw `n_windows` windows of `n_cols` pileup columns.
 
     Returns float32 ``(n_windows, n_cols, 10)`` (and int64 labels
-    ``(n_windows, n_cols)`` when `return_labels`).
+    ``(n_windows, n_cols)`` when `return_labels`).  With `raw` the un-normalised
+    pileup is returned instead, as the reference's `pileup_counts` hands it to
+    `_post_process_pileup`: dict(counts uint16 (W,T,10), depth uint32 (W,T) = depth of
+    the parent major column, major / minor int64 (W,T) position fields).
     """
     rng = np.random.default_rng(seed)
     out = np.zeros((n_windows, n_cols, NUM_FEATURES), dtype=np.float32)
     labels = np.zeros((n_windows, n_cols), dtype=np.int64)
+    raw_depth = np.ones((n_windows, n_cols), dtype=np.uint32)
+    raw_major = np.zeros((n_windows, n_cols), dtype=np.int64)
+    raw_minor = np.zeros((n_windows, n_cols), dtype=np.int64)
     for w in range(n_windows):
         # --- column skeleton: every reference position gives a major column,
         # followed by a minor column when at least one read inserts there.
@@ -73,7 +79,14 @@ def counts_windows(n_windows, n_cols, depth=60, seed=1234, p_sub=0.01,
         col_depth = np.ones(n_cols, dtype=np.float32)
         col_depth[start[keep]] = depth_pos[keep]
         col_depth[mcols] = depth_pos[mk]
-        out[w] /= col_depth[:, None]
+        raw_depth[w] = col_depth.astype(np.uint32)
+        raw_major[w, start[keep]] = np.nonzero(keep)[0]
+        raw_major[w, mcols] = np.nonzero(mk)[0]
+        raw_minor[w, mcols] = 1
+        if not raw:
+            out[w] /= col_depth[:, None]
+    if raw:
+        return dict(counts=out.astype(np.uint16), depth=raw_depth, major=raw_major, minor=raw_minor)
     if return_labels:
         return out, labels
     return out

@@ -133,6 +133,39 @@ def main():
         dec[key] = np.array(seqs)
     np.savez_compressed(os.path.join(GOLD, "consensus_decode.npz"), **dec)
 
+    # f2 / f3: raw counts -> reference CountsFeatureEncoder._post_process_pileup
+    # (features.py:871-935, normalise='total') -> reference model -> reference decode_consensus with
+    # qualities (labels.py:1053-1085).  Depth 300 windows give non-trivial quotients.
+    fe = medaka.features.CountsFeatureEncoder()
+    diet = {}
+    for name, (W, T, depth, seed) in {"d60": (3, 700, 60, 91), "d300": (2, 500, 300, 92)}.items():
+        raw = synth.counts_windows(W, T, depth=depth, seed=seed, raw=True)
+        feats, depths, seqs, quals = [], [], [], []
+        for w in range(W):
+            pos = np.empty(T, dtype=[("major", int), ("minor", int)])
+            pos["major"], pos["minor"] = raw["major"][w], raw["minor"][w]
+            region = medaka.common.Region("synth", int(pos["major"][0]), int(pos["major"][-1]) + 1)
+            smp = fe._post_process_pileup(raw["counts"][w].astype(np.uint64), pos, region)
+            feats.append(smp.features)
+            depths.append(smp.depth)
+        feats = np.stack(feats)
+        assert feats.dtype == np.float32
+        probs = predict(load(trained, 1.0), feats)
+        for w in range(W):
+            s = _S()
+            s.label_probs = probs[w]
+            seq, q = ls.decode_consensus(s, with_qualities=True)
+            seqs.append(seq)
+            quals.append(q)
+        diet[f"{name}/counts"] = raw["counts"]
+        diet[f"{name}/depth"] = np.stack(depths).astype(np.uint32)
+        diet[f"{name}/features"] = feats
+        diet[f"{name}/probs"] = probs
+        diet[f"{name}/seq"] = np.array(seqs)
+        diet[f"{name}/qual"] = np.array(quals)
+        assert np.array_equal(diet[f"{name}/depth"], raw["depth"]), "synthetic depth != reference depth"
+    np.savez_compressed(os.path.join(GOLD, "pcie_diet.npz"), **diet)
+
     # report how degenerate each weight set is
     for key in ("init/uniform", "x3/uniform", "trained/synth60"):
         p = out[key]

@@ -117,3 +117,29 @@ def make_torch_oracle(state=None, num_features=10, gru_size=128, n_layers=2,
 
 def state_to_numpy(state_dict):
     return {k: v.detach().cpu().numpy().copy() for k, v in state_dict.items()}
+
+
+def normalise_counts(counts, depth):
+    """CountsFeatureEncoder(normalise='total') -- reference medaka/features.py:907-911 and :926:
+    integer counts / max(1, depth of the parent major column), numpy true division (float64),
+    then `.astype(float32)`.  counts (..., F) integer, depth (...) integer."""
+    counts = np.asarray(counts).astype(np.uint64)
+    depth = np.asarray(depth).astype(np.uint64)
+    return (counts / np.maximum(1, depth)[..., None]).astype(np.float32)
+
+
+def decode_consensus(label_probs, symbols="*ACGT", with_gaps=False, with_qualities=False, cap=70.0):
+    """HaploidLabelScheme.decode_consensus for one sample -- reference medaka/labels.py:1053-1085
+    with `_phred` (labels.py:388-402): argmax, probability of the argmax class, gaps dropped,
+    qualities = chr(uint8(min(-10 log10(clip(1 - p, 10^-7, 1)), 70)) + 33)."""
+    mp = np.argmax(label_probs, -1)
+    probs = np.take_along_axis(label_probs, np.expand_dims(mp, -1), -1).squeeze(-1)
+    if not with_gaps:
+        mask = mp != symbols.index("*")
+        mp, probs = mp[mask], probs[mask]
+    seq = np.array([ord(x) for x in symbols], dtype="u1")[mp].tobytes().decode()
+    if not with_qualities:
+        return seq
+    err = np.clip(1 - probs, 10 ** (-cap / 10.0), 1)
+    q = np.minimum(-10 * np.log10(err), cap)
+    return seq, (q.astype("u1") + 33).tobytes().decode()

@@ -72,6 +72,10 @@ def install():
             def buffer(obj, n=None):
                 return bytes(obj[:n]) if n is not None else bytes(obj)
 
+            @staticmethod
+            def string(obj):      # features.py:671 reads the channel codes through ffi.string
+                return bytes(obj)
+
             def __getattr__(self, name):
                 return lambda *a, **k: None
 

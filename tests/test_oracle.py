@@ -92,3 +92,17 @@ def test_oracle_against_live_reference(gold):
     ref = m.predict_on_batch(te.Batch(counts_matrix=torch.from_numpy(x))).numpy()
     assert np.abs(oracle.c_gru_forward(x, st) - ref).max() <= TOL
     assert np.abs(oracle.make_torch_oracle(st).predict(x).numpy() - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["d60", "d300"])
+def test_normalise_and_decode_restatements_match_reference(name):
+    """f2/f3 oracles against the unmodified reference's `_post_process_pileup` (features.py:871-935)
+    and `decode_consensus(with_qualities=True)` (labels.py:1053-1085), oracle/make_golden.py."""
+    import os
+    from conftest import GOLD
+    d = np.load(os.path.join(GOLD, "pcie_diet.npz"))
+    feats = oracle.normalise_counts(d[f"{name}/counts"], d[f"{name}/depth"])
+    assert feats.dtype == np.float32 and np.array_equal(feats, d[f"{name}/features"])
+    for w in range(feats.shape[0]):
+        seq, qual = oracle.decode_consensus(d[f"{name}/probs"][w], with_qualities=True)
+        assert seq == str(d[f"{name}/seq"][w]) and qual == str(d[f"{name}/qual"][w])

@@ -277,6 +277,66 @@ def test_majority_vote_model(gold):
                   oracle.c_majority_forward(gold["gru_inputs"]["uniform"])).max() <= 2e-7
 
 
+# ---- device-side normalisation and decode ---------------------------------
+@pytest.mark.parametrize("name", ["d60", "d300"])
+def test_counts_in_decoded_out_matches_reference(gold, engines, name):
+    import os
+    from conftest import GOLD
+    d = np.load(os.path.join(GOLD, "pcie_diet.npz"))
+    counts, depth = d[f"{name}/counts"], d[f"{name}/depth"]
+    e = engines("trained")
+    # f2: the device's normalisation is bit-identical to the reference's float64-divide-then-round
+    L = engine._lib.load()
+    n_cols = counts.shape[0] * counts.shape[1]
+    cd, dd, xd = engine.DeviceBuffer(counts.nbytes), engine.DeviceBuffer(depth.nbytes), engine.DeviceBuffer(n_cols * 40)
+    cd.upload(np.ascontiguousarray(counts)); dd.upload(np.ascontiguousarray(depth))
+    engine._lib.check(L.mdk_normalise_counts_dev(cd.ptr, dd.ptr, n_cols, 10, xd.ptr, 0, None), "normalise")
+    x = xd.download((counts.shape[0], counts.shape[1], 10), np.float32)
+    assert np.array_equal(x, d[f"{name}/features"])
+    for b in (cd, dd, xd):
+        b.free()
+    # whole path: raw counts in, probabilities + decoded classes out
+    probs, cls, pmax = e.forward_counts_host(counts, depth, probs=True, decoded=True)
+    assert np.array_equal(probs, e.forward_host(d[f"{name}/features"]))
+    _check(probs, d[f"{name}/probs"], what=f"counts-in {name}")
+    # f3: first-maximum argmax and its probability, bit for bit
+    assert np.array_equal(cls, probs.argmax(-1)) and np.array_equal(pmax, probs.max(-1))
+    cls2, pmax2 = e.forward_decoded_host(d[f"{name}/features"])
+    assert np.array_equal(cls2, cls) and np.array_equal(pmax2, pmax)
+    n_q = n_bad = 0
+    for w in range(cls.shape[0]):
+        seq, qual = engine.decode_consensus(cls[w], pmax[w], with_qualities=True)
+        assert (seq, qual) == oracle.decode_consensus(probs[w], with_qualities=True)
+        assert seq == str(d[f"{name}/seq"][w])                      # identical consensus
+        ref_q = str(d[f"{name}/qual"][w])
+        n_q += len(ref_q)
+        n_bad += sum(a != b for a, b in zip(qual, ref_q))
+    assert n_bad <= 0.01 * n_q       # a quality char may sit on a truncation boundary of -10 log10(1 - p)
+    # model-level entry
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_set(gold, "trained").items()})
+    m = m.to("cuda").eval()
+    assert np.array_equal(m.predict_on_counts(counts, depth).numpy(), probs)
+    c3, p3 = m.predict_on_counts(torch.from_numpy(counts.astype(np.int32)).to(torch.int32).numpy().astype(np.uint16),
+                                 depth, decoded=True)
+    assert np.array_equal(c3.numpy(), cls) and np.array_equal(p3.numpy(), pmax)
+
+
+def test_decode_nan_and_ties_follow_numpy():
+    L = engine._lib.load()
+    p = np.array([[0.2, 0.5, 0.5, 0.1, 0.0], [np.nan, 0.9, 0.0, 0.0, 0.1], [0.1, np.nan, 0.9, np.nan, 0.0],
+                  [0.2, 0.2, 0.2, 0.2, 0.2]], dtype=np.float32)
+    pd, cd, md = engine.DeviceBuffer(p.nbytes), engine.DeviceBuffer(4), engine.DeviceBuffer(16)
+    pd.upload(p)
+    engine._lib.check(L.mdk_decode_dev(pd.ptr, 4, 5, cd.ptr, md.ptr, 0, None), "decode")
+    cls = cd.download((4,), np.uint8)
+    pm = md.download((4,), np.float32)
+    assert cls.tolist() == np.argmax(p, -1).tolist() == [1, 0, 1, 0]
+    assert np.array_equal(pm, np.take_along_axis(p, np.argmax(p, -1)[:, None], -1)[:, 0], equal_nan=True)
+    for b in (pd, cd, md):
+        b.free()
+
+
 # ---- read-level model (reference LatentSpaceLSTM) -------------------------------------------------
 import os  # noqa: E402
 from conftest import GOLD  # noqa: E402
