@@ -445,7 +445,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             const dim3 grid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF>), grid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
-                       in, Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi, Ld.up_scale_rec)
+                       in, Ld.wih_frag, Ld.bias_gi, m->gi, n_tiles, T, D, Ld.inv_scale_gi, Ld.up_scale_rec, kActScale)
             if (D == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
             else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ bias,    // [D][NG*128]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
-    const float *__restrict__ out_scale_p)
+    const float *__restrict__ out_scale_p, float a_scale)   // a_scale: power-of-two operand scale of act_in
 {
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 _Float16 a, b;
-                split_f16(v[i] * kActScale, a, b);
+                split_f16(v[i] * a_scale, a, b);
                 hi[i] = a; lo[i] = b;
             }
             const int row = 4 * g + 2 * q + (tau & 1), mt = tau >> 1;

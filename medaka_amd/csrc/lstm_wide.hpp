@@ -58,7 +58,11 @@ __device__ __forceinline__ float dpp_mov(float v) {
 //     [C_A(t) + G_B(t-1)]  barrier  [C_B(t) + G_A(t)]  barrier     (C = compute + publish, G = gather)
 // NGRP = 1: one group per cluster, the exchange latency is exposed every step -- used while the batch
 // has no more groups than clusters (then more clusters run in parallel instead).
-template <int PF, int NGRP, int ABL = 0>
+// HP: half precision (`TorchModel.half()`): fp16 operands without the hi/lo split -- one A row per
+// window, so a group is 16 windows (4 per lane), 12 MFMAs per wave and step, W_hi only; a granule
+// carries the fp16 h of TWO windows (2wp, 2wp+1), which makes the exchange byte-for-byte the same
+// code as the (hi, lo) granules of the fp32-parity mode.
+template <int PF, int NGRP, bool HP = false, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const float *__restrict__ gi,       // [B*T][1536] permuted gate columns, bias folded, PRE-SCALED by S
     const half8 *__restrict__ wfrag,    // [12 members][8 waves][12 ks][2 hi/lo][64]
@@ -77,14 +81,17 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const int cluster = (idx / kWC) * 8 + xcd, member = idx % kWC;
     if (cluster >= n_clusters) return;
     const int c = lane & 15, g = lane >> 4, gate = c >> 2, u4 = c & 3;
+    constexpr int NQ = HP ? 4 : 2;          // windows per lane
+    constexpr int NS = HP ? 1 : 2;          // fp16 pieces per operand
+    constexpr int GW = 4 * NQ;              // windows per group
 
-    half8 wf[kWKS][2];
+    half8 wf[kWKS][NS];
     {
         const half8 *wp = wfrag + ((size_t)(member * 8 + w8) * (kWKS * 2)) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < kWKS; ++ks)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) wf[ks][sp] = wp[(size_t)(ks * 2 + sp) * 64];
+            for (int sp = 0; sp < NS; ++sp) wf[ks][sp] = wp[(size_t)(ks * 2 + sp) * 64];
     }
     constexpr float L2E = 1.44269504088896340736f;
     // sigmoid(x) = rcp(1 + exp2(-x log2e));  tanh(x) = 1 - 2 rcp(1 + exp2(2x log2e)):  a*r + b
@@ -144,20 +151,20 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
 #pragma unroll
     for (int ks = 0; ks < kWKS; ++ks)
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][sp]));
+        for (int sp = 0; sp < NS; ++sp) asm volatile("" ::"v"(wf[ks][sp]));
 
     unsigned int tag = 0;
     for (int it = cluster; it < n_units; it += n_clusters) {   // unit = NGRP consecutive 8-window groups
-        const float *gp[2][2];
-        float *op[2][2];
-        bool wok[2][2];
-        float cst[2][2];
-        float gq[2][PF][2];
+        const float *gp[2][NQ];
+        float *op[2][NQ];
+        bool wok[2][NQ];
+        float cst[2][NQ];
+        float gq[2][PF][NQ];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                int win = (NGRP * it + x) * kWWin + 2 * g + q;
+            for (int q = 0; q < NQ; ++q) {
+                int win = (NGRP * it + x) * GW + NQ * g + q;
                 wok[x][q] = win < B;
                 if (!wok[x][q]) win = B - 1;
                 gp[x][q] = gi + ((size_t)win * T + t_first) * kWG4 + col;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
         }
         auto refill = [&](int x, int p, bool advance) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if constexpr (ABL & 1) gq[x][p][q] = 0.f; else gq[x][p][q] = gp[x][q][0];
                 if (advance) gp[x][q] += gstride;
             }
@@ -180,14 +187,18 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) { gq[x][p][0] = 0.f; gq[x][p][1] = 0.f; }
+            for (int p = 0; p < PF; ++p)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) gq[x][p][q] = 0.f;
 #pragma unroll
             for (int p = 0; p + 1 < PF; ++p) refill(x, p, p + 1 < T);
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int p = 0; p + 1 < PF; ++p) { asm volatile("" ::"v"(gq[x][p][0])); asm volatile("" ::"v"(gq[x][p][1])); }
+            for (int p = 0; p + 1 < PF; ++p)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(gq[x][p][q]));
         __syncthreads();
 
         // One half-step: compute + publish step `tag` of group x, and gather step `gtag` of the OTHER
@@ -243,19 +254,26 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
                 const half8 a1 = *reinterpret_cast<const half8 *>(rb + (ks + 1) * kHKStride + rd_off);
                 acc0 = mfma16(a0, wf[ks][0], acc0);
                 acc1 = mfma16(a1, wf[ks + 1][0], acc1);
-                acc0 = mfma16(a0, wf[ks][1], acc0);
-                acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+                if constexpr (!HP) {
+                    acc0 = mfma16(a0, wf[ks][1], acc0);
+                    acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+                }
             }
-            float act[2];
+            // rows of the accumulator: fp32-parity mode 2q + {hi, lo} of window 2g + q; half mode window 4g + q
+            float act[NQ];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float pre = gq[x][p][q] + ((acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]));
+            for (int q = 0; q < NQ; ++q) {
+                float dot;
+                if constexpr (HP) dot = acc0[q] + acc1[q];
+                else dot = (acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]);
+                const float pre = gq[x][p][q] + dot;
                 const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * k_act));
                 act[q] = __builtin_fmaf(a_act, r, b_act);
             }
             unsigned long long *dst = ex + (size_t)(2 * x + (tag & 1)) * kWGranules;
+            unsigned int payload[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 // lane c (< 4) holds i; f, g, o come from lanes c+4, c+8, c+12 of the same row
                 const float fv = dpp_mov<0x104>(act[q]);     // row_shl:4
                 const float gv = dpp_mov<0x108>(act[q]);     // row_shl:8
@@ -264,23 +282,33 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
                 cst[x][q] = cv;
                 const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
                 const float h = ov * tc;
-                _Float16 hi, lo;
-                split_f16(h * kActScale, hi, lo);
+                if constexpr (HP) {
+                    const unsigned int hb = __builtin_bit_cast(unsigned short, (_Float16)(h * kActScale));
+                    if (q & 1) payload[q >> 1] |= hb << 16; else payload[q >> 1] = hb;
+                } else {
+                    _Float16 hi, lo;
+                    split_f16(h * kActScale, hi, lo);
+                    payload[q] = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                                 ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+                }
                 if (c < 4) {
-                    const unsigned int payload = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
-                                                 ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned long long gran = ((unsigned long long)tag << 32) | payload;
-                    if constexpr (!(ABL & 4)) {
-                        if (same_xcd)
-                            __hip_atomic_store(dst + (2 * g + q) * kWH + unit, gran, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the shared L2
-                        else
-                            __hip_atomic_store(dst + (2 * g + q) * kWH + unit, gran, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
-                    }
                     if constexpr (!(ABL & 8)) { if (step < T && wok[x][q]) op[x][q][0] = h; }
                 }
                 op[x][q] += ostride;
+            }
+            if (c < 4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {     // granule row 2g + j: (window, hi|lo) or a pair of windows
+                    const unsigned long long gran = ((unsigned long long)tag << 32) | payload[j];
+                    if constexpr (!(ABL & 4)) {
+                        if (same_xcd)
+                            __hip_atomic_store(dst + (2 * g + j) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the shared L2
+                        else
+                            __hip_atomic_store(dst + (2 * g + j) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NGRP == 1 && !(ABL & 4)) {
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
 constexpr int kWGemmRows = 64;
 constexpr int kWGemmBlk = kWGemmRows * 16 + 16;   // one (k-step, lane-group) block of an image + pad
 
-template <int KS>
+template <int KS, bool HP = false>   // HP: one fp16 product, hi image only
 __global__ __launch_bounds__(512, 1) void k_gemm_rows(
     const float *__restrict__ A, const half8 *__restrict__ wfrag, const float *__restrict__ bias,
     float *__restrict__ out, long M, float a_scale, float alpha)
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_rows(
             hi[i] = a; lo[i] = b;
         }
         *reinterpret_cast<half8 *>(ahi + k8 * kWGemmBlk + row * 16) = hi;
-        *reinterpret_cast<half8 *>(alo + k8 * kWGemmBlk + row * 16) = lo;
+        if constexpr (!HP) *reinterpret_cast<half8 *>(alo + k8 * kWGemmBlk + row * 16) = lo;
     }
     __syncthreads();
 
@@ -381,18 +409,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_rows(
             for (int j = 0; j < 3; ++j) {
                 const half8 *wp = wfrag + (((size_t)(nt0 + j) * KS + ks) * 2) * 64 + lane;
                 bh[j] = wp[0];
-                bl[j] = wp[64];
+                if constexpr (!HP) bl[j] = wp[64];
             }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int off = (ks * 4 + g) * kWGemmBlk + (mt * 16 + c) * 16;
                 const half8 ah = *reinterpret_cast<const half8 *>(ahi + off);
-                const half8 al = *reinterpret_cast<const half8 *>(alo + off);
+                half8 al;
+                if constexpr (!HP) al = *reinterpret_cast<const half8 *>(alo + off);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     acc[mt][j] = mfma16(ah, bh[j], acc[mt][j]);
-                    acc[mt][j] = mfma16(al, bh[j], acc[mt][j]);
-                    acc[mt][j] = mfma16(ah, bl[j], acc[mt][j]);
+                    if constexpr (!HP) {
+                        acc[mt][j] = mfma16(al, bh[j], acc[mt][j]);
+                        acc[mt][j] = mfma16(ah, bl[j], acc[mt][j]);
+                    }
                 }
             }
         }

@@ -32,6 +32,7 @@ struct LstmLayer {
     half8 *wih_frag = nullptr;   // [D][8][K/32][4][2][64]
     float *bias = nullptr;       // [D][512]  b_ih + b_hh
     float *inv_rec = nullptr, *up_rec = nullptr, *inv_gi = nullptr;   // [D]
+    float a_scale = kActScale;   // operand scale of this layer's input activations
 };
 
 // one uni-directional LSTM(384) layer of the wide model (lstm_wide.hpp)
@@ -55,9 +56,9 @@ struct mdk_rl {
     int opt_poll_delay = 7;      // wide model, one group per cluster: 64-clock sleeps before the first poll
     // front end
     float *base_emb = nullptr, *strand_emb = nullptr, *w1 = nullptr, *b1 = nullptr, *a1 = nullptr, *c1 = nullptr;
-    half8 *w2frag = nullptr, *w3frag = nullptr;
-    float *b2 = nullptr, *a2 = nullptr, *c2 = nullptr, *b3 = nullptr;
-    float s1 = 1.f, inv2 = 1.f, s2 = 1.f, inv3 = 1.f;
+    half8 *w2frag = nullptr;
+    float *b2 = nullptr, *a2 = nullptr, *c2 = nullptr;
+    float s1 = 1.f, inv2 = 1.f, s2 = 1.f;   // s2: operand scale of the pooled conv features
     int nf = 7;
     // recurrent stack + head
     bool wide = false;           // lstm_size == 384: cluster recurrence (lstm_wide.hpp)
@@ -81,8 +82,8 @@ extern "C" void mdk_rl_destroy(mdk_rl *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     for (void *p : {(void *)m->base_emb, (void *)m->strand_emb, (void *)m->w1, (void *)m->b1, (void *)m->a1,
-                    (void *)m->c1, (void *)m->w2frag, (void *)m->w3frag, (void *)m->b2, (void *)m->a2,
-                    (void *)m->c2, (void *)m->b3, (void *)m->lin_w, (void *)m->lin_b, (void *)m->mask,
+                    (void *)m->c1, (void *)m->w2frag, (void *)m->b2, (void *)m->a2,
+                    (void *)m->c2, (void *)m->lin_w, (void *)m->lin_b, (void *)m->mask,
                     (void *)m->gi, (void *)m->act[0], (void *)m->act[1], (void *)m->x_dev,
                     (void *)m->p_dev})
         free_dev(p);
@@ -96,20 +97,40 @@ extern "C" void mdk_rl_destroy(mdk_rl *m) {
     delete m;
 }
 
-static int build_lstm_layer(LstmLayer &Ld, int K, int D, int reverse_mask, const float *const *w) {
+// fold: the pre-pool Linear (w_pp [128][128], b_pp [128]) when this is the first layer -- mean-pooling
+// and the linear layer commute and nothing non-linear separates it from W_ih, so the front end pools
+// the conv features and this layer projects them with W_ih W_pp (bias W_ih b_pp + b_ih + b_hh).
+static int build_lstm_layer(LstmLayer &Ld, int K, int D, int reverse_mask, const float *const *w,
+                            const float *w_pp = nullptr, const float *b_pp = nullptr, float a_scale = kActScale) {
     constexpr int NG = 4, G4 = 4 * kH;
-    Ld.K = K; Ld.D = D; Ld.reverse_mask = reverse_mask;
+    Ld.K = K; Ld.D = D; Ld.reverse_mask = reverse_mask; Ld.a_scale = a_scale;
     const int KS = K / 32;
     std::vector<half8> whh((size_t)D * 8 * 4 * NG * 2 * 64), wih((size_t)D * 8 * KS * NG * 2 * 64);
-    std::vector<float> bias((size_t)D * G4), inv_rec(D), up_rec(D), inv_gi(D);
+    std::vector<float> bias((size_t)D * G4), inv_rec(D), up_rec(D), inv_gi(D), wfold;
     for (int d = 0; d < D; ++d) {
         const float *w_ih = w[4 * d + 0], *w_hh = w[4 * d + 1], *b_ih = w[4 * d + 2], *b_hh = w[4 * d + 3];
         for (int j = 0; j < G4; ++j) bias[(size_t)d * G4 + j] = b_ih[j] + b_hh[j];
+        if (w_pp) {
+            wfold.assign((size_t)G4 * K, 0.f);
+            std::vector<double> row(K);
+            for (int j = 0; j < G4; ++j) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bj = (double)b_ih[j] + (double)b_hh[j];
+                for (int k = 0; k < kH; ++k) {
+                    const double a = w_ih[(size_t)j * kH + k];
+                    bj += a * b_pp[k];
+                    for (int c = 0; c < K; ++c) row[c] += a * w_pp[(size_t)k * K + c];
+                }
+                for (int c = 0; c < K; ++c) wfold[(size_t)j * K + c] = (float)row[c];
+                bias[(size_t)d * G4 + j] = (float)bj;
+            }
+            w_ih = wfold.data();
+        }
         const float sw = pick_scale(w_hh, (size_t)G4 * kH);
         inv_rec[d] = 1.0f / (kActScale * sw);
         up_rec[d] = kActScale * sw;
         const float swi = pick_scale(w_ih, (size_t)G4 * K);
-        inv_gi[d] = 1.0f / (kActScale * swi);
+        inv_gi[d] = 1.0f / (a_scale * swi);
         for (int w8 = 0; w8 < 8; ++w8)
             for (int gate = 0; gate < NG; ++gate)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -236,8 +257,7 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
         std::vector<float> be(w[0], w[0] + A * 6), se(w[1], w[1] + 18), w1(128 * 8, 0.f);
         for (int c = 0; c < 128; ++c)
             for (int f = 0; f < nf; ++f) w1[c * 8 + f] = w[2][(size_t)c * nf + f];
-        std::vector<float> b1(w[3], w[3] + 128), a1(128), c1(128), b2(w[9], w[9] + 128), a2(128), c2(128),
-            b3(w[15], w[15] + 128);   // (wide model: the linear layer is folded into the LSTM, w3/b3 unused)
+        std::vector<float> b1(w[3], w[3] + 128), a1(128), c1(128), b2(w[9], w[9] + 128), a2(128), c2(128);
         for (int c = 0; c < 128; ++c) {
             a1[c] = w[4][c] / std::sqrt(w[7][c] + eps);
             c1[c] = w[5][c] - w[6][c] * a1[c];
@@ -267,10 +287,8 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
             y2max = std::max(y2max, std::max(std::fabs(c2[co]), std::fabs(a2[co] * bound + c2[co])));
         }
         m->s2 = pick_scale_max(y2max);
-        const float sw3 = pick_scale(w[14], (size_t)desc->lstm_size * 128);
-        m->inv3 = 1.0f / (m->s2 * sw3);
         // conv2 B-fragments [17][4 kb][4 waves][2 nt][2][64]: W2[co][ci][tau]
-        std::vector<half8> w2f((size_t)kRlTaps * 4 * 4 * 2 * 2 * 64), w3f((size_t)4 * 4 * 2 * 2 * 64);
+        std::vector<half8> w2f((size_t)kRlTaps * 4 * 4 * 2 * 2 * 64);
         for (int tau = 0; tau < kRlTaps; ++tau)
             for (int kb = 0; kb < 4; ++kb)
                 for (int wv = 0; wv < 4; ++wv)
@@ -287,24 +305,10 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
                             const size_t base = (((((size_t)tau * 4 + kb) * 4 + wv) * 2 + nt) * 2) * 64 + lane;
                             w2f[base] = hi; w2f[base + 64] = lo;
                         }
-        for (int ks = 0; ks < 4; ++ks)
-            for (int wv = 0; wv < 4; ++wv)
-                for (int nt = 0; nt < 2; ++nt)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int j = 32 * wv + 16 * nt + (lane & 15), gq = lane >> 4;
-                        half8 hi, lo;
-                        for (int i = 0; i < 8; ++i) {
-                            _Float16 a, b;
-                            split_host(w[14][(size_t)j * 128 + 32 * ks + 8 * gq + i] * sw3, a, b);
-                            hi[i] = a; lo[i] = b;
-                        }
-                        const size_t base = ((((size_t)ks * 4 + wv) * 2 + nt) * 2) * 64 + lane;
-                        w3f[base] = hi; w3f[base + 64] = lo;
-                    }
         if ((rc = upload(&m->base_emb, be)) || (rc = upload(&m->strand_emb, se)) || (rc = upload(&m->w1, w1)) ||
             (rc = upload(&m->b1, b1)) || (rc = upload(&m->a1, a1)) || (rc = upload(&m->c1, c1)) ||
             (rc = upload(&m->w2frag, w2f)) || (rc = upload(&m->b2, b2)) || (rc = upload(&m->a2, a2)) ||
-            (rc = upload(&m->c2, c2)) || (rc = upload(&m->w3frag, w3f)) || (rc = upload(&m->b3, b3)))
+            (rc = upload(&m->c2, c2)))
             return bail(rc);
     }
     // ---- LSTM stack
@@ -339,18 +343,20 @@ extern "C" int mdk_rl_create(const mdk_rl_desc *desc, const float *const *w, int
         HIP_TRY(hipMalloc((void **)&m->exch, kWExchWords * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&m->status, 64));
         HIP_TRY(hipMemset(m->status, 0, 64));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<12>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<12, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 12 * 4 * kWGemmBlk));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * kWGemmBlk));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_rows<12, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 12 * 4 * kWGemmBlk));
     } else if (desc->bidirectional) {
         m->layers.resize(2);
-        if ((rc = build_lstm_layer(m->layers[0], 128, 2, 2, w + 16))) return bail(rc);
+        if ((rc = build_lstm_layer(m->layers[0], 128, 2, 2, w + 16, w[14], w[15], m->s2))) return bail(rc);
         if ((rc = build_lstm_layer(m->layers[1], 256, 2, 2, w + 24))) return bail(rc);
     } else {
         m->layers.resize(4);   // reverse - forward - reverse - forward (latent_space_lstm.py:141-149)
         for (int i = 0; i < 4; ++i)
-            if ((rc = build_lstm_layer(m->layers[i], 128, 1, (i % 2 == 0) ? 1 : 0, w + 16 + 4 * i))) return bail(rc);
+            if ((rc = build_lstm_layer(m->layers[i], 128, 1, (i % 2 == 0) ? 1 : 0, w + 16 + 4 * i,
+                                       i == 0 ? w[14] : nullptr, i == 0 ? w[15] : nullptr, i == 0 ? m->s2 : kActScale)))
+                return bail(rc);
     }
     {
         const int Dl = desc->bidirectional ? 2 : 1;
@@ -434,13 +440,16 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     RlFrontArgs fa;
     fa.x = x_dev; fa.mask = m->mask; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
     fa.w1 = m->w1; fa.b1 = m->b1; fa.a1 = m->a1; fa.c1 = m->c1; fa.w2frag = m->w2frag; fa.b2 = m->b2; fa.a2 = m->a2;
-    fa.c2 = m->c2; fa.w3frag = nullptr; fa.b3 = nullptr; fa.pooled = m->act[1];   // (B, P, 128) rows
+    fa.c2 = m->c2; fa.pooled = m->act[1];   // (B, P, 128) rows
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
-    fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
-    hipLaunchKernelGGL(k_rl_front<false>, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    fa.s1 = m->s1; fa.inv2 = m->inv2;
+    const bool hp = (m->precision == MDK_PREC_FP16);
+    if (hp) hipLaunchKernelGGL((k_rl_front<false, true>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL((k_rl_front<false, false>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
 
-    // up to 16 groups of 8 windows: one group per cluster; more: two interleaved groups per cluster
-    const int n_groups = (B + kWWin - 1) / kWWin;
+    // groups of 8 windows (16 in half precision); up to 16 groups: one per cluster; more: two interleaved
+    const int gw = hp ? 2 * kWWin : kWWin;
+    const int n_groups = (B + gw - 1) / gw;
     int ngrp = n_groups > kWMaxClusters ? 2 : 1;
     if (m->opt_wide_groups == 1 || m->opt_wide_groups == 2) ngrp = m->opt_wide_groups;
     const int n_units = (n_groups + ngrp - 1) / ngrp;
@@ -451,17 +460,22 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     for (size_t l = 0; l < m->wlayers.size(); ++l) {
         const WideLayer &Ld = m->wlayers[l];
         float *outp = m->act[l & 1];
-        if (Ld.KS == 4)
-            hipLaunchKernelGGL(k_gemm_rows<4>, dim3(gemm_grid), dim3(512), (size_t)2 * 4 * 4 * kWGemmBlk, s, in,
-                               Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha);
-        else
-            hipLaunchKernelGGL(k_gemm_rows<12>, dim3(gemm_grid), dim3(512), (size_t)2 * 12 * 4 * kWGemmBlk, s, in,
-                               Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha);
+#define MDK_WGEMM(KSV, HPF)                                                                              \
+    hipLaunchKernelGGL((k_gemm_rows<KSV, HPF>), dim3(gemm_grid), dim3(512), (size_t)2 * KSV * 4 * kWGemmBlk, s, in, \
+                       Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha)
+        if (Ld.KS == 4) { if (hp) MDK_WGEMM(4, true); else MDK_WGEMM(4, false); }
+        else { if (hp) MDK_WGEMM(12, true); else MDK_WGEMM(12, false); }
+#undef MDK_WGEMM
         HIP_TRY(hipMemsetAsync(m->exch, 0, kWExchWords * sizeof(unsigned long long), s));
-#define MDK_WIDE_N(NG, ABLV)                                                                             \
-    hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, ABLV>), dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, outp, \
-                       m->exch, m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_units, m->opt_force_wt, m->opt_poll_delay)
-#define MDK_WIDE(ABLV) do { if (ngrp == 2) MDK_WIDE_N(2, ABLV); else MDK_WIDE_N(1, ABLV); } while (0)
+#define MDK_WIDE_N(NG, HPF, ABLV)                                                                        \
+    hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, HPF, ABLV>), dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, \
+                       outp, m->exch, m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_units, m->opt_force_wt, \
+                       m->opt_poll_delay)
+#define MDK_WIDE(ABLV)                                                                                   \
+    do {                                                                                                 \
+        if (hp) { if (ngrp == 2) MDK_WIDE_N(2, true, ABLV); else MDK_WIDE_N(1, true, ABLV); }            \
+        else { if (ngrp == 2) MDK_WIDE_N(2, false, ABLV); else MDK_WIDE_N(1, false, ABLV); }             \
+    } while (0)
 #ifdef MDK_WIDE_ABLATE   // timing experiments only (profiles/): MDK_WIDE_ABL selects a garbage-result variant
         switch (getenv("MDK_WIDE_ABL") ? atoi(getenv("MDK_WIDE_ABL")) : 0) {
             case 1: MDK_WIDE(1); break;
@@ -469,7 +483,6 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
             case 3: MDK_WIDE(3); break;
             case 4: MDK_WIDE(4); break;
             case 5: MDK_WIDE(5); break;
-            case 13: MDK_WIDE(13); break;
             default: MDK_WIDE(0);
         }
 #else
@@ -521,10 +534,11 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
     RlFrontArgs fa;
     fa.x = x_dev; fa.mask = m->mask; fa.base_emb = m->base_emb; fa.strand_emb = m->strand_emb;
     fa.w1 = m->w1; fa.b1 = m->b1; fa.a1 = m->a1; fa.c1 = m->c1; fa.w2frag = m->w2frag; fa.b2 = m->b2; fa.a2 = m->a2;
-    fa.c2 = m->c2; fa.w3frag = m->w3frag; fa.b3 = m->b3; fa.pooled = m->act[0];
+    fa.c2 = m->c2; fa.pooled = m->act[0];
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
-    fa.s1 = m->s1; fa.inv2 = m->inv2; fa.s2 = m->s2; fa.inv3 = m->inv3;
-    hipLaunchKernelGGL(k_rl_front<true>, dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    fa.s1 = m->s1; fa.inv2 = m->inv2;
+    if (hp) hipLaunchKernelGGL((k_rl_front<true, true>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL((k_rl_front<true, false>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
 
     // ---- LSTM stack
     const int n_win = n_tiles * kTileWin;
@@ -543,7 +557,7 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
         const dim3 ggrid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF, 4>), ggrid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
-                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec)
+                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale)
         if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM

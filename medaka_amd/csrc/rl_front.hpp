@@ -3,7 +3,9 @@
 //
 //   uint8 (B, P, D, F) -> Embedding(base) + Embedding(strand+1) (+) q/25-1 (+ dwell)     7|8 features
 //   -> Conv1d(k=1) -> ReLU -> BatchNorm1d -> Conv1d(k=17, pad 8) -> ReLU -> BatchNorm1d  (per read)
-//   -> Linear(128 -> 128) -> mean over the non-empty reads                               (B, P, 128)
+//   -> mean over the non-empty reads                                                     (B, P, 128)
+//   [-> Linear(128 -> lstm_size): commutes with the mean and no non-linearity separates it from
+//       W_ih of the first LSTM, so the host folds it into that projection (rl_api.hip)]
 //
 // One fused kernel, nothing per-read is ever written to HBM (the per-read activations would be
 // 512 B x B x D x P).  A work-group owns (window b, 64 positions) and walks the reads:
@@ -12,9 +14,9 @@
 //   2. conv2 as an implicit GEMM on the matrix cores: M = 64 positions, N = 128 channels,
 //      K = 17 taps x 128 channels = 68 k-steps; the A fragment of tap tau is the same LDS tile
 //      read tau rows further down; W2 B-fragments stream from L2 (pre-packed);
-//   3. bias + ReLU + BN in registers, re-split into LDS, Linear(128->128) as a second small MFMA
-//      GEMM, accumulated over reads in registers (empty reads are skipped: their mask is 0);
-//   4. mean, bias, store in the tile-major activation layout the LSTM projection GEMM reads.
+//   3. bias + ReLU + BN in registers, accumulated over the reads in registers (empty reads are
+//      skipped: their mask is 0);
+//   4. mean, store in the layout the LSTM projection GEMM reads.
 // fp32 parity through the same fp16 hi/lo split as the GRU kernels (three products, fp32
 // accumulate); BatchNorm is folded to y = a*x + c at load time (eval mode).
 #pragma once
@@ -75,18 +77,16 @@ struct RlFrontArgs {
     const float *b1, *a1, *c1;     // [128] conv1 bias, BN1 scale, BN1 shift
     const half8 *w2frag;           // [17][4 kb][4 waves][2 nt][2 hi/lo][64]
     const float *b2, *a2, *c2;     // [128]
-    const half8 *w3frag;           // [4 ks][4 waves][2 nt][2 hi/lo][64]
-    const float *b3;               // [128]
-    float *pooled;                 // LIN: act_t layout, D = 1;  !LIN: natural [B][P][128]
+    float *pooled;                 // TILED: act_t layout, D = 1;  else natural [B][P][128]
     int B, P, Dp, F, nf, n_alpha;
-    float s1, inv2, s2, inv3;      // operand scales (powers of two)
+    float s1, inv2;                // operand scales (powers of two)
 };
 
-// LIN = true : Linear(128 -> 128) per read, pooled, + bias, tile-major store (lstm_size = 128);
-// LIN = false: the BN2 output itself is mean-pooled and stored as natural (B, P, 128) rows -- the
-//              linear layer commutes with the mean and is folded into the first LSTM projection
-//              by the host (rl_api.hip, wide model).
-template <bool LIN>
+// TILED: store in the tile-major activation layout (layout.hpp, D = 1; lstm_size 128) instead of
+// natural (B, P, 128) rows (lstm_size 384).
+// HP: half precision (`TorchModel.half()`): conv2 as ONE fp16 product instead of the three of the
+// hi/lo split (the reference's own half mode runs these convolutions in fp16 under autocast).
+template <bool TILED, bool HP = false>
 __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];   // 43.5 KB
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
             _Float16 hi, lo;
             split_f16(v * A.s1, hi, lo);
             *reinterpret_cast<_Float16 *>(yhi + r * kRlRowBytes + ci * 2) = hi;
-            *reinterpret_cast<_Float16 *>(ylo + r * kRlRowBytes + ci * 2) = lo;
+            if constexpr (!HP) *reinterpret_cast<_Float16 *>(ylo + r * kRlRowBytes + ci * 2) = lo;
         }
         __syncthreads();
         // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks
@@ -185,38 +185,27 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     bh[nt] = wk[(nt * 2 + 0) * 64];
-                    bl[nt] = wk[(nt * 2 + 1) * 64];
+                    if constexpr (!HP) bl[nt] = wk[(nt * 2 + 1) * 64];
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int off = (16 * mt + n + tau) * kRlRowBytes + (32 * kb + 8 * g) * 2;
                     const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
-                    const half8 al = *reinterpret_cast<const half8 *>(ylo + off);
+                    half8 al;
+                    if constexpr (!HP) al = *reinterpret_cast<const half8 *>(ylo + off);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                        if constexpr (!HP) {
+                            acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                            acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                        }
                     }
                 }
             }
         }
         __syncthreads();   // everybody is done reading the conv1 tile
-        if constexpr (!LIN) {
-            // ---- 3'. bias + ReLU + BN2, pooled directly
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = fmaf(acc[mt][nt][r], A.inv2, b2v[nt]);
-                        v = fmaxf(v, 0.f);
-                        pool[mt][nt][r] += fmaf(a2v[nt], v, c2v[nt]);
-                    }
-            continue;
-        }
-        // ---- 3a. bias + ReLU + BN2, re-split as the A operand of the linear layer
+        // ---- 3. bias + ReLU + BN2, accumulated over the reads in registers
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -225,81 +214,27 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
                 for (int r = 0; r < 4; ++r) {
                     float v = fmaf(acc[mt][nt][r], A.inv2, b2v[nt]);
                     v = fmaxf(v, 0.f);
-                    v = fmaf(a2v[nt], v, c2v[nt]);
-                    _Float16 hi, lo;
-                    split_f16(v * A.s2, hi, lo);
-                    const int row = 16 * mt + 4 * g + r, co = 32 * w + 16 * nt + n;
-                    *reinterpret_cast<_Float16 *>(yhi + row * kRlRowBytes + co * 2) = hi;
-                    *reinterpret_cast<_Float16 *>(ylo + row * kRlRowBytes + co * 2) = lo;
+                    pool[mt][nt][r] += fmaf(a2v[nt], v, c2v[nt]);
                 }
-        __syncthreads();
-        // ---- 3b. Linear(128 -> 128), accumulated over reads
-        floatx4 acc3[4][2];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc3[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 bh[2], bl[2];
-            const half8 *wk = A.w3frag + ((size_t)(ks * 4 + w) * 4) * 64 + lane;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                bh[nt] = wk[(nt * 2 + 0) * 64];
-                bl[nt] = wk[(nt * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int off = (16 * mt + n) * kRlRowBytes + (32 * ks + 8 * g) * 2;
-                const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
-                const half8 al = *reinterpret_cast<const half8 *>(ylo + off);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    acc3[mt][nt] = mfma16(ah, bh[nt], acc3[mt][nt]);
-                    acc3[mt][nt] = mfma16(al, bh[nt], acc3[mt][nt]);
-                    acc3[mt][nt] = mfma16(ah, bl[nt], acc3[mt][nt]);
-                }
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pool[mt][nt][r] = fmaf(acc3[mt][nt][r], A.inv3, pool[mt][nt][r]);
-        __syncthreads();   // the tile is rewritten by the next read
     }
 
-    // ---- 4. mean over reads (+ bias), store
+    // ---- 4. mean over the non-empty reads, store
     const float inv_n = 1.0f / (float)n_reads_s;     // 0 reads -> inf/nan, as the reference's 0/0
-    if constexpr (!LIN) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int co = 32 * w + 16 * nt + n;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = p0 + 16 * mt + 4 * g + r;
-                    if (t < A.P) A.pooled[((size_t)b * A.P + t) * kRlC + co] = pool[mt][nt][r] * inv_n;
-                }
-        }
-        return;
-    }
-    const int tile = b >> 3, wt = b & 7, gl = wt >> 1, ql = wt & 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int j = 32 * w + 16 * nt + n;          // output feature
-        const float b3v = A.b3[j];
-        const int w8 = j >> 4, c = j & 15;
+        const int co = 32 * w + 16 * nt + n;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = p0 + 16 * mt + 4 * g + r;
-                if (t < A.P)
-                    A.pooled[act_block(1, tile, A.P, t) + act_in_block(0, w8, ql, gl * 16 + c)] =
-                        fmaf(pool[mt][nt][r], inv_n, b3v);
+                if (t < A.P) {
+                    if constexpr (TILED)   // window b = tile b>>3, lane group (b&7)>>1, q = b&1
+                        A.pooled[act_block(1, b >> 3, A.P, t) + act_in_block(0, co >> 4, b & 1, ((b & 7) >> 1) * 16 + (co & 15))] =
+                            pool[mt][nt][r] * inv_n;
+                    else
+                        A.pooled[((size_t)b * A.P + t) * kRlC + co] = pool[mt][nt][r] * inv_n;
+                }
             }
     }
 }

@@ -474,3 +474,24 @@ def test_wide_read_level_model_api_and_integration(wide_state):
     with pytest.raises(RuntimeError, match="bidirectional"):
         engine.RlEngine(rl_oracle.synth_rl_state(seed=1, lstm_size=384, bidirectional=True, use_dwells=False),
                         lstm_size=384, bidirectional=True)
+
+
+@pytest.mark.parametrize("B,P,D", [(5, 300, 6), (40, 130, 3), (300, 20, 2)])
+def test_wide_read_level_half_precision(B, P, D, wide_state):
+    """`half()` on the LSTM(384) model: single-product fp16 front end / GEMMs and 16-window groups in
+    the cluster recurrence (1, 3 and 19 groups: one per cluster, then two interleaved)."""
+    x = rl_oracle.synth_reads(B, P, D, use_dwells=True, seed=B + P)
+    ref = rl_oracle.rl_forward(x, wide_state, use_dwells=True, bidirectional=False)
+    e = engine.RlEngine(wide_state, **WIDE_KW)
+    e.set_precision(True)
+    out = e.forward_host(x)
+    e.set_precision(False)
+    full = e.forward_host(x)
+    e.close()
+    _check(full, ref, what="rl_lstm384 back to fp32")
+    assert np.isfinite(out).all() and np.abs(out.sum(-1) - 1).max() <= 1e-5
+    assert np.abs(out - ref).max() <= 2e-2
+    assert np.abs(out - ref).mean() <= 1e-3
+    srt = np.sort(ref, -1)
+    clear = (srt[..., -1] - srt[..., -2]) > 4e-2
+    assert (out.argmax(-1) == ref.argmax(-1))[clear].all()
