@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MDK_LIB_OUT") or os.path.join(HERE, "libmedaka_amd.so")
 SOURCES = ["api.hip", "rl_api.hip"]
 HEADERS = ["common.hpp", "layout.hpp", "host_common.hpp", "rec_mfma.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
-           "rl_front.hpp",
+           "rl_front.hpp", "lstm_wide.hpp",
            os.path.join("..", "..", "include", "medaka_amd.h")]
 
 
@@ -35,12 +35,20 @@ def build(force=False, verbose=False, extra_flags=()):
     """Compile for gfx950.  Returns the path of the shared library."""
     if not force and not needs_build():
         return LIB
+    # several ranks may get here at once (bench.py under torch.distributed.run): each compiles into
+    # its own temporary and renames it into place atomically, so nobody ever loads a partial file
+    tmp = f"{LIB}.tmp.{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-ffp-contract=off",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + list(extra_flags)
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + list(extra_flags)
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

@@ -430,7 +430,8 @@ def test_wide_read_level_goldens_from_unmodified_reference(name, wide_state):
     _check(out, cases[f"{name}/y"], what=f"rl_lstm384 {name}")
 
 
-@pytest.mark.parametrize("B,P,D", [(1, 1, 1), (1, 33, 2), (8, 70, 4), (9, 129, 5), (17, 64, 3)])
+@pytest.mark.parametrize("B,P,D", [(1, 1, 1), (1, 33, 2), (8, 70, 4), (9, 129, 5), (17, 64, 3),
+                                   (264, 16, 2)])     # 33 groups -> 17 pairs on 16 clusters: a cluster loops
 def test_wide_read_level_shapes_vs_oracle(B, P, D, wide_state):
     x = rl_oracle.synth_reads(B, P, D, use_dwells=True, seed=5 * B + P + D)
     ref = rl_oracle.rl_forward(x, wide_state, use_dwells=True, bidirectional=False)
