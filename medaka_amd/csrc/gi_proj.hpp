@@ -95,7 +95,8 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const float *__restrict__ bias,    // [D][NG*128]
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
-    const float *__restrict__ out_scale_p, float a_scale)   // a_scale: power-of-two operand scale of act_in
+    const float *__restrict__ out_scale_p, float a_scale,   // a_scale: power-of-two operand scale of act_in
+    int strip0)                                              // first 8-step strip of this launch
 {
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, tile fastest
     const int tile = blockIdx.x % n_tiles;
-    const int strip = blockIdx.x / n_tiles;
+    const int strip = strip0 + blockIdx.x / n_tiles;
     const int t0 = strip * kGemmSteps;
 
     // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)

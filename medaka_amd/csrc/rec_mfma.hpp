@@ -56,7 +56,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ b_hn,    // [D][128]  (unscaled)
     float *__restrict__ out,           // act_t (layout.hpp)
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p, int reverse_mask,
-    const int *__restrict__ cond, int want)
+    const int *__restrict__ cond, int want,
+    int s0, int ns)   // steps [s0, s0 + ns) of the scan (scan step s is t = s, or T-1-s when reversed);
+                      // s0 > 0 resumes from the h this kernel stored at scan step s0 - 1 (GRU only)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     // NQ*g + q of it.  Layout tiles are 8 windows (layout.hpp): window w -> tile w>>3,
     // lane-group (w&7)>>1, q (w&7)&1.
     const long tstep = reverse ? -1 : 1;
-    const int t_first = reverse ? (T - 1) : 0;
+    const int s_end = s0 + ns;
+    const int t_first = reverse ? (T - 1 - s0) : s0;
     const float *gp[NQ];
     float *op[NQ];
 #pragma unroll
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     // is always refilled one step after it was consumed, from inside the MFMA phase
 #pragma unroll
     for (int p = 0; p + 1 < PF; ++p) {
-        refill(p, p + 1 < T);
+        refill(p, s0 + p + 1 < s_end);
     }
 #pragma unroll
     for (int p = 0; p + 1 < PF; ++p) {
@@ -189,6 +192,25 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     }
     asm volatile("" ::"v"(bhn));
     __syncthreads();
+    if constexpr (CELL == 0) {
+        if (s0 > 0) {   // resume: h of scan step s0 - 1 from the output, and its fp16 image
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float h = *(op[q] - ostride);
+                hprev[q] = h;
+                _Float16 hi, lo;
+                split_f16(h * kActScale, hi, lo);
+                unsigned char *img = hbuf + (s0 & 1) * kHBufBytes + wr_off;
+                if constexpr (HP) {
+                    *reinterpret_cast<_Float16 *>(img + q * 16) = hi;
+                } else {
+                    *reinterpret_cast<_Float16 *>(img + (2 * q) * 16) = hi;
+                    *reinterpret_cast<_Float16 *>(img + (2 * q + 1) * 16) = lo;
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     floatx4 xar = floatx4{0.f, 0.f, 0.f, 0.f}, xaz = xar, xgn = xar;
     if constexpr (XIN && !(ABL & 1)) {
@@ -213,11 +235,11 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     };
     if constexpr (ABL & 64) tprev = __builtin_amdgcn_s_memtime();
 
-    for (int step0 = 0; step0 < T; step0 += PF) {
+    for (int step0 = s0; step0 < s_end; step0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int step = step0 + p;
-            {   // steps >= T (T not a multiple of PF) run too, with their stores masked
+            {   // steps >= s_end (ns not a multiple of PF) run too, with their stores masked
                 const int cur = (step & 1) * kHBufBytes;
                 const int nxt = kHBufBytes - cur;
                 stamp(0);   // refill issue + loop overhead
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     }
                     // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
                     // vector-memory issue hides under the MFMAs; unconditional, in ring order
-                    refill((p + PF - 1) % PF, (step + PF) < T);
+                    refill((p + PF - 1) % PF, (step + PF) < s_end);
                     // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
                     // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
                     // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                             const float h = ((rows(ar, q) + rows(az, q)) + (rows(anh, q) + rows(anl, q))) * 1e-6f +
                                             (rr[q] + zz[q] + gnv[q]) * 1e-9f;
                             hprev[q] = h; hn[q] = h;
-                            if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
+                            if constexpr (!(ABL & 16)) { if (step < s_end) op[q][0] = h; }
                             continue;
                         }
                         float tn;
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
                         hprev[q] = h;
                         hn[q] = h;
-                        if constexpr (!(ABL & 16)) { if (step < T) op[q][0] = h; }
+                        if constexpr (!(ABL & 16)) { if (step < s_end) op[q][0] = h; }
                     }
                 } else {
                     // ---- LSTM cell: i, f, g tiles first; the o tile last, with the cell update
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                             ag = mfma16(a[ks], wf[ks][2][sp], ag);
                         }
                     }
-                    refill((p + PF - 1) % PF, (step + PF) < T);
+                    refill((p + PF - 1) % PF, (step + PF) < s_end);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(to * c_sig));
                         const float h = ov * tc[q];
                         hn[q] = h;
-                        if (step < T) op[q][0] = h;
+                        if (step < s_end) op[q][0] = h;
                     }
                 }
                 if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain

@@ -557,14 +557,14 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
         const dim3 ggrid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF, 4>), ggrid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
-                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale)
+                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale, 0)
         if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM
 #define MDK_REC(NQV, HPF)                                                                          \
     hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, false, HPF, 1, 0>), rgrid, dim3(512), 0, s, m->gi, \
                        (const half8 *)nullptr, (const half8 *)nullptr, Ld.whh_frag, Ld.bias, outp, n_tiles, T, D, \
-                       Ld.inv_rec, Ld.reverse_mask, (const int *)nullptr, 0)
+                       Ld.inv_rec, Ld.reverse_mask, (const int *)nullptr, 0, 0, T)
         if (hp) { if (nq == 1) MDK_REC(1, true); else if (nq == 2) MDK_REC(2, true); else MDK_REC(4, true); }
         else { if (nq == 1) MDK_REC(1, false); else MDK_REC(2, false); }
 #undef MDK_REC

@@ -129,6 +129,23 @@ def test_multi_pass_batches_agree_bitwise(gold):
     _check(one, oracle.c_gru_forward(x, weight_set(gold, "x3")), what="multi-pass")
 
 
+def test_overlapped_projection_agrees_bitwise(gold):
+    """Layer 0's recurrence in resumable chunks with layer 1's projection GEMM on a side stream
+    (api.hip, forward_pass) is the same arithmetic as the plain sequence: identical bits, for the
+    fused and the unfused (fallback: raw counts) layer-0 paths."""
+    x = synth.counts_windows(11, 2048, seed=61)
+    for scale in (1.0, 3000.0):
+        xs = x * np.float32(scale)
+        e = engine.GruEngine(weight_set(gold, "trained"))
+        a = e.forward_host(xs)
+        e.set_option("overlap_gemm", 0)
+        b = e.forward_host(xs)
+        e.close()
+        assert np.array_equal(a, b), scale
+    _check(a if scale == 1.0 else engine.GruEngine(weight_set(gold, "trained")).forward_host(x),
+           oracle.c_gru_forward(x, weight_set(gold, "trained")), what="overlapped")
+
+
 def test_fused_and_unfused_layer0_agree(gold):
     x = synth.counts_windows(9, 400, seed=41)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
