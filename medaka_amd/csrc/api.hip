@@ -450,7 +450,8 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // GEMM runs (chip clock drops with the extra power draw -- padding its LDS so that no GEMM
     // work-group can share its CUs changed nothing), at B >= 1000 there are no idle CUs and no gain.
     const bool overlap = m->opt_overlap && D == 2 && L >= 2 && !(abl != 0 && !hp && nq <= 2) &&
-                         T >= 2048 && T % (2 * kGemmSteps) == 0;
+                         T >= 2048 && T % (2 * kGemmSteps) == 0 &&
+                         n_wg * D <= 160;   // only while the recurrence leaves a good part of the 256 CUs idle
     const float *gi_l1 = m->gi;
     bool gemm_done = false;
     constexpr int kOvChunks = 6;   // (a finer, shrinking schedule measured no better: the GEMM is the longer leg)
