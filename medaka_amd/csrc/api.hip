@@ -441,6 +441,19 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM
     };
+    // classifier head over the columns [t0, t0 + nt) of every window
+    auto launch_head = [&](const float *src, hipStream_t st, int t0, int nt) {
+        if (nt <= 0) return;
+        const long n_blocks = (long)n_tiles * nt;
+        const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
+        if (D == 2)
+            hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, st, src, m->lin_w, m->lin_b,
+                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt);
+        else
+            hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, st, src, m->lin_w, m->lin_b,
+                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt);
+    };
+    bool head_done = false;
     // Overlap plan (bidirectional, >= 2 layers): gi of layer 1 at column t needs layer 0's forward h_t
     // (ready after scan step t) and backward h_t (ready after scan step T-1-t), i.e. columns
     // [T-s, s) after s steps.  The second half of layer 0's recurrence is cut into chunks; after each,
@@ -462,7 +475,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             HIP_TRY(hipMalloc((void **)&m->gi2, (size_t)D * rows * kG * sizeof(float)));
             m->gi2_rows = rows;
         }
-        while (m->ov_ev.size() < kOvChunks + 2) {
+        while (m->ov_ev.size() < 2 * (kOvChunks + 1)) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             m->ov_ev.push_back(e);
@@ -542,8 +555,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
             }
 #undef MDK_ABL_CASE
-        } else if (overlap && l == 0) {
-            // first half in one launch, second half in chunks with the layer-1 projection behind them
+        } else if (overlap && (l == 0 || l == L - 1)) {
+            // first half in one launch, second half in chunks; behind each chunk, on the side stream,
+            // what the newly complete columns [T-s', T-s) + [s, s') feed: layer 1's projection (l = 0)
+            // or the classifier head (last layer)
             int bounds[kOvChunks + 2];
             bounds[0] = 0;
             for (int j = 0; j <= kOvChunks; ++j)
@@ -555,17 +570,25 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 if (fuse) { launch(true, cond, 0); launch_fallback(cond); }
                 else launch(false, nullptr, 0);
                 if (j == 0) continue;          // after T/2 steps no column has both directions yet
-                HIP_TRY(hipEventRecord(m->ov_ev[j], s));
-                HIP_TRY(hipStreamWaitEvent(m->side, m->ov_ev[j], 0));
-                if (j == 1 && (rc = tm.begin(SLOT_GI0 + 1, m->side, &gspan))) return rc;
-                const LayerDev &L1 = m->layers[1];
-                launch_gemm(L1, outp, m->gi2, m->side, (T - bounds[j + 1]) / kGemmSteps, (bounds[j + 1] - bounds[j]) / kGemmSteps);
-                launch_gemm(L1, outp, m->gi2, m->side, bounds[j] / kGemmSteps, (bounds[j + 1] - bounds[j]) / kGemmSteps);
+                hipEvent_t ev = m->ov_ev[(l == 0 ? 0 : kOvChunks + 1) + j];
+                HIP_TRY(hipEventRecord(ev, s));
+                HIP_TRY(hipStreamWaitEvent(m->side, ev, 0));
+                const int lo0 = T - bounds[j + 1], hi0 = bounds[j], len = bounds[j + 1] - bounds[j];
+                if (l == 0) {
+                    if (j == 1 && (rc = tm.begin(SLOT_GI0 + 1, m->side, &gspan))) return rc;
+                    launch_gemm(m->layers[1], outp, m->gi2, m->side, lo0 / kGemmSteps, len / kGemmSteps);
+                    launch_gemm(m->layers[1], outp, m->gi2, m->side, hi0 / kGemmSteps, len / kGemmSteps);
+                } else {
+                    launch_head(outp, m->side, lo0, len);
+                    launch_head(outp, m->side, hi0, len);
+                }
             }
-            if ((rc = tm.end_at(gspan))) return rc;
-            HIP_TRY(hipEventRecord(m->ov_ev[0], m->side));
-            HIP_TRY(hipStreamWaitEvent(s, m->ov_ev[0], 0));
-            gemm_done = true;
+            if (l == 0 && (rc = tm.end_at(gspan))) return rc;
+            hipEvent_t done = m->ov_ev[l == 0 ? 0 : kOvChunks + 1];
+            HIP_TRY(hipEventRecord(done, m->side));
+            HIP_TRY(hipStreamWaitEvent(s, done, 0));
+            if (l == 0) gemm_done = true;
+            if (l == L - 1) head_done = true;
             m->last.rec_launches += kOvChunks;   // (+1 below)
         } else if (fuse) {
             launch(true, cond, 0);     // fused: runs unless the range flag is up
@@ -579,16 +602,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         in = outp;
     }
     if ((rc = tm.begin(SLOT_HEAD))) return rc;
-    {
-        const long n_blocks = (long)n_tiles * T;
-        const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
-        if (D == 2)
-            hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
-                               probs, nb, T, n_tiles, m->desc.normalise);
-        else
-            hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
-                               probs, nb, T, n_tiles, m->desc.normalise);
-    }
+    if (!head_done) launch_head(in, s, 0, T);
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
     return MDK_OK;

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_head_tiled(
     const float *__restrict__ lin_w,  // [5][DIN*128]
     const float *__restrict__ lin_b,  // [5]
     float *__restrict__ probs,        // [B][T][5]
-    int B, int T, int n_tiles, int normalise)
+    int B, int T, int n_tiles, int normalise,
+    int t0, int nt)                   // columns [t0, t0 + nt) of every window
 {
     constexpr int F = DIN * 128;
     __shared__ __attribute__((aligned(16))) float wl[5 * F];
@@ -103,12 +104,12 @@ __global__ __launch_bounds__(256) void k_head_tiled(
     float bv[5];
 #pragma unroll
     for (int cl = 0; cl < 5; ++cl) bv[cl] = lin_b[cl];
-    const long n_blocks = (long)n_tiles * T;
+    const long n_blocks = (long)n_tiles * nt;
     const long wave_global = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long n_waves = (long)gridDim.x * (blockDim.x >> 6);
     for (long blk = wave_global; blk < n_blocks; blk += n_waves) {
-        const int tile = (int)(blk / T), t = (int)(blk % T);
-        const float *src = act + (size_t)blk * (DIN * 1024) + 4 * lane;
+        const int tile = (int)(blk / nt), t = t0 + (int)(blk % nt);
+        const float *src = act + ((size_t)tile * T + t) * (DIN * 1024) + 4 * lane;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < DIN * 4; ++i) {
