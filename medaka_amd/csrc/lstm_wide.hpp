@@ -6,8 +6,11 @@
 // per step.  So the hidden units are split over a CLUSTER of 12 work-groups (= 12 CUs):
 //
 //   * member m owns units [32m, 32m+32) of all four gates = 128 gate columns; its wave w8 owns the
-//     16-column MFMA tile [i u0..3 | f u0..3 | g u0..3 | o u0..3], u = 32m + 4*w8 + 0..3, with the
-//     W_hh fragments of that tile resident in registers (12 k-steps x hi/lo = 96 VGPRs);
+//     16 gate columns (i, f, g, o) x units 32m + 4*w8 + 0..3 with their W_hh fragments resident in
+//     registers (12 k-steps x hi/lo = 96 VGPRs).  W is the *A* operand of the MFMA (rows = gate
+//     columns ordered 4*unit + gate) and h the B operand (columns = windows), so the accumulator
+//     of lane (g, c) is exactly (i, f, g, o) of unit g for window c: the cell update needs no
+//     cross-lane traffic (fp32-parity mode: one DPP add joins the hi and lo columns of a window);
 //   * every step each member needs the WHOLE h_{t-1} (8 windows x 384 units).  Members publish their
 //     32 units as 8-byte {fp16 hi, fp16 lo, step tag} granules with one agent-scope relaxed atomic
 //     store each (= `global_store_dwordx2 sc1`, visible across CUs and XCDs without any fence),
@@ -19,9 +22,6 @@
 //     uses (rec_mfma.hpp), 12 k-steps long; rows = (window, hi|lo) as there;
 //   * two 8-window groups are interleaved per cluster so that one group's exchange latency is
 //     covered by the other group's MFMAs;
-//   * the four gates of a unit sit in four lanes of one 16-lane row: activations are computed by
-//     all lanes (per-lane sigmoid/tanh constants), moved with three DPP row shifts, and lanes
-//     0..3 of each row finish the cell (c, h) for windows 2g+q.
 //
 // Cluster members must be co-resident (they spin on each other): the grid is 8 XCDs x 2 clusters
 // x 12 members = 192 work-groups <= 256 CUs, one per CU, launched on an otherwise idle device;
@@ -80,10 +80,11 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int cluster = (idx / kWC) * 8 + xcd, member = idx % kWC;
     if (cluster >= n_clusters) return;
-    const int c = lane & 15, g = lane >> 4, gate = c >> 2, u4 = c & 3;
-    constexpr int NQ = HP ? 4 : 2;          // windows per lane
+    const int c = lane & 15, g = lane >> 4;   // accumulator: rows 4g..4g+3 = gates of unit g, column c
     constexpr int NS = HP ? 1 : 2;          // fp16 pieces per operand
-    constexpr int GW = 4 * NQ;              // windows per group
+    constexpr int GW = HP ? 16 : 8;         // windows per group: column c = window (HP) or 2*window + {hi, lo}
+    const int wl = HP ? c : (c >> 1);       // this lane's window within the group
+    const bool lead = HP || !(c & 1);       // fp32-parity: the hi column's lane finishes the cell
 
     half8 wf[kWKS][NS];
     {
@@ -94,11 +95,9 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             for (int sp = 0; sp < NS; ++sp) wf[ks][sp] = wp[(size_t)(ks * 2 + sp) * 64];
     }
     constexpr float L2E = 1.44269504088896340736f;
-    // sigmoid(x) = rcp(1 + exp2(-x log2e));  tanh(x) = 1 - 2 rcp(1 + exp2(2x log2e)):  a*r + b
-    const float k_act = (gate == 2 ? 2.0f : -1.0f) * L2E * inv_scale;
-    const float a_act = gate == 2 ? -2.0f : 1.0f, b_act = gate == 2 ? 1.0f : 0.0f;
-    const int col = (member * 8 + w8) * 16 + c;      // permuted gi column of this lane
-    const int unit = 32 * member + 4 * w8 + u4;      // meaningful in the gate-0 lanes (c < 4)
+    const float c_sig = -L2E * inv_scale, c_tanh = 2.0f * L2E * inv_scale;
+    const int col = (member * 8 + w8) * 16 + 4 * g;  // permuted gi columns (i, f, g, o) of this lane's unit
+    const int unit = 32 * member + 4 * w8 + g;
     unsigned long long *ex = exch + (size_t)cluster * (4 * kWGranules);
     if (tid < 2) s_abort[tid] = 0;
 
@@ -155,22 +154,20 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
 
     unsigned int tag = 0;
     for (int it = cluster; it < n_units; it += n_clusters) {   // unit = NGRP consecutive 8-window groups
-        const float *gp[2][NQ];
-        float *op[2][NQ];
-        bool wok[2][NQ];
-        float cst[2][NQ];
-        float gq[2][PF][NQ];
+        const float *gp[2];
+        float *op[2];
+        bool wok[2];
+        float cst[2];
+        float4 gq[2][PF];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                int win = (NGRP * it + x) * GW + NQ * g + q;
-                wok[x][q] = win < B;
-                if (!wok[x][q]) win = B - 1;
-                gp[x][q] = gi + ((size_t)win * T + t_first) * kWG4 + col;
-                op[x][q] = out + ((size_t)win * T + t_first) * kWH + unit;
-                cst[x][q] = 0.f;
-            }
+        for (int x = 0; x < 2; ++x) {
+            int win = (NGRP * it + x) * GW + wl;
+            wok[x] = win < B;
+            if (!wok[x]) win = B - 1;
+            gp[x] = gi + ((size_t)win * T + t_first) * kWG4 + col;
+            op[x] = out + ((size_t)win * T + t_first) * kWH + unit;
+            cst[x] = 0.f;
+        }
         __syncthreads();                                  // previous pair's images are dead
 #pragma unroll
         for (int x = 0; x < 2; ++x) {   // h_0 = 0: the images the first step reads
@@ -178,27 +175,24 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
         }
         auto refill = [&](int x, int p, bool advance) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if constexpr (ABL & 1) gq[x][p][q] = 0.f; else gq[x][p][q] = gp[x][q][0];
-                if (advance) gp[x][q] += gstride;
-            }
+            if constexpr (ABL & 1) gq[x][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else gq[x][p] = *reinterpret_cast<const float4 *>(gp[x]);
+            if (advance) gp[x] += gstride;
         };
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) gq[x][p][q] = 0.f;
+            for (int p = 0; p < PF; ++p) gq[x][p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int p = 0; p + 1 < PF; ++p) refill(x, p, p + 1 < T);
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int p = 0; p + 1 < PF; ++p)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(gq[x][p][q]));
+            for (int p = 0; p + 1 < PF; ++p) {
+                asm volatile("" ::"v"(gq[x][p].x)); asm volatile("" ::"v"(gq[x][p].y));
+                asm volatile("" ::"v"(gq[x][p].z)); asm volatile("" ::"v"(gq[x][p].w));
+            }
         __syncthreads();
 
         // One half-step: compute + publish step `tag` of group x, and gather step `gtag` of the OTHER
@@ -252,64 +246,57 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             for (int ks = 0; ks < kWKS; ks += 2) {
                 const half8 a0 = *reinterpret_cast<const half8 *>(rb + ks * kHKStride + rd_off);
                 const half8 a1 = *reinterpret_cast<const half8 *>(rb + (ks + 1) * kHKStride + rd_off);
-                acc0 = mfma16(a0, wf[ks][0], acc0);
-                acc1 = mfma16(a1, wf[ks + 1][0], acc1);
+                acc0 = mfma16(wf[ks][0], a0, acc0);          // A = W (rows = gate columns), B = h (columns = windows)
+                acc1 = mfma16(wf[ks + 1][0], a1, acc1);
                 if constexpr (!HP) {
-                    acc0 = mfma16(a0, wf[ks][1], acc0);
-                    acc1 = mfma16(a1, wf[ks + 1][1], acc1);
+                    acc0 = mfma16(wf[ks][1], a0, acc0);
+                    acc1 = mfma16(wf[ks + 1][1], a1, acc1);
                 }
             }
-            // rows of the accumulator: fp32-parity mode 2q + {hi, lo} of window 2g + q; half mode window 4g + q
-            float act[NQ];
+            // acc[r] = gate r (i, f, g, o) of unit g for column c; fp32-parity: add the lo column (lane c ^ 1)
+            float pre[4];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float dot;
-                if constexpr (HP) dot = acc0[q] + acc1[q];
-                else dot = (acc0[2 * q] + acc0[2 * q + 1]) + (acc1[2 * q] + acc1[2 * q + 1]);
-                const float pre = gq[x][p][q] + dot;
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * k_act));
-                act[q] = __builtin_fmaf(a_act, r, b_act);
+            for (int r = 0; r < 4; ++r) {
+                float dot = acc0[r] + acc1[r];
+                if constexpr (!HP) dot += dpp_mov<0xB1>(dot);     // quad_perm:[1,0,3,2]
+                pre[r] = dot;
+            }
+            const float4 gv4 = gq[x][p];
+            const float iv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[0] + gv4.x) * c_sig));
+            const float fv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[1] + gv4.y) * c_sig));
+            const float gg = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[2] + gv4.z) * c_tanh)), 1.0f);
+            const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[3] + gv4.w) * c_sig));
+            const float cv = __builtin_fmaf(fv, cst[x], iv * gg);
+            cst[x] = cv;
+            const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
+            const float h = ov * tc;
+            unsigned int payload;
+            if constexpr (HP) {   // a granule carries windows (2wp, 2wp + 1): take the odd neighbour's half
+                const unsigned int hb = __builtin_bit_cast(unsigned short, (_Float16)(h * kActScale));
+                const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xf, 0xf, true);
+                payload = hb | (nb << 16);
+            } else {
+                _Float16 hi, lo;
+                split_f16(h * kActScale, hi, lo);
+                payload = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                          ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
             }
             unsigned long long *dst = ex + (size_t)(2 * x + (tag & 1)) * kWGranules;
-            unsigned int payload[2];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                // lane c (< 4) holds i; f, g, o come from lanes c+4, c+8, c+12 of the same row
-                const float fv = dpp_mov<0x104>(act[q]);     // row_shl:4
-                const float gv = dpp_mov<0x108>(act[q]);     // row_shl:8
-                const float ov = dpp_mov<0x10C>(act[q]);     // row_shl:12
-                const float cv = __builtin_fmaf(fv, cst[x][q], act[q] * gv);
-                cst[x][q] = cv;
-                const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
-                const float h = ov * tc;
-                if constexpr (HP) {
-                    const unsigned int hb = __builtin_bit_cast(unsigned short, (_Float16)(h * kActScale));
-                    if (q & 1) payload[q >> 1] |= hb << 16; else payload[q >> 1] = hb;
-                } else {
-                    _Float16 hi, lo;
-                    split_f16(h * kActScale, hi, lo);
-                    payload[q] = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
-                                 ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
-                }
-                if (c < 4) {
-                    if constexpr (!(ABL & 8)) { if (step < T && wok[x][q]) op[x][q][0] = h; }
-                }
-                op[x][q] += ostride;
-            }
-            if (c < 4) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {     // granule row 2g + j: (window, hi|lo) or a pair of windows
-                    const unsigned long long gran = ((unsigned long long)tag << 32) | payload[j];
-                    if constexpr (!(ABL & 4)) {
-                        if (same_xcd)
-                            __hip_atomic_store(dst + (2 * g + j) * kWH + unit, gran, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the shared L2
-                        else
-                            __hip_atomic_store(dst + (2 * g + j) * kWH + unit, gran, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
-                    }
+            if (!(c & 1)) {       // granule row c >> 1: (window, hi|lo) or a pair of windows
+                const unsigned long long gran = ((unsigned long long)tag << 32) | payload;
+                if constexpr (!(ABL & 4)) {
+                    if (same_xcd)
+                        __hip_atomic_store(dst + (c >> 1) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the shared L2
+                    else
+                        __hip_atomic_store(dst + (c >> 1) * kWH + unit, gran, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
                 }
             }
+            if (lead) {
+                if constexpr (!(ABL & 8)) { if (step < T && wok[x]) op[x][0] = h; }
+            }
+            op[x] += ostride;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NGRP == 1 && !(ABL & 4)) {
                 // own group, just published: a poll that misses costs a second L2 round trip, so give the

@@ -169,7 +169,7 @@ static int build_lstm_layer(LstmLayer &Ld, int K, int D, int reverse_mask, const
 
 // Wide layer: w_ih is [1536][K] (K = 128 for the folded first layer, 384 after), w_hh [1536][384],
 // bias [1536] already summed.  Gate columns are permuted into the order k_lstm_wide's waves own:
-// tile nt = member * 8 + wave, column n of the tile = gate (n >> 2) of unit 32*member + 4*wave + (n & 3).
+// tile nt = member * 8 + wave, column n of the tile = gate (n & 3) of unit 32*member + 4*wave + (n >> 2).
 static int build_wide_layer(WideLayer &Ld, int K, const float *w_ih, const float *w_hh, const float *bias,
                             float a_scale, int reverse) {
     Ld.KS = K / 32; Ld.reverse = reverse; Ld.a_scale = a_scale;
@@ -184,7 +184,7 @@ static int build_wide_layer(WideLayer &Ld, int K, const float *w_ih, const float
         const int member = nt / 8, w8 = nt % 8;
         for (int lane = 0; lane < 64; ++lane) {
             const int n = lane & 15, kg = lane >> 4;
-            const int j = (n >> 2) * kWH + 32 * member + 4 * w8 + (n & 3);
+            const int j = (n & 3) * kWH + 32 * member + 4 * w8 + (n >> 2);
             if (kg == 0) bp[nt * 16 + n] = bias[j] * up_rec;
             for (int ks = 0; ks < kWKS; ++ks) {
                 half8 hi, lo;
@@ -483,6 +483,8 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
             case 3: MDK_WIDE(3); break;
             case 4: MDK_WIDE(4); break;
             case 5: MDK_WIDE(5); break;
+            case 8: MDK_WIDE(8); break;
+            case 9: MDK_WIDE(9); break;
             default: MDK_WIDE(0);
         }
 #else
