@@ -207,7 +207,7 @@ def main():
                                    "head": statistics.mean(head_ms[-args.steps:]),
                                    "device_total": statistics.mean(total_ms[-args.steps:])},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and ranks.world == 1:   # the CPU baseline is a single-GPU-run figure
             n = min(args.cpu_sample, B)
             probs = out_holder["y"][:n].cpu().numpy()
             result["cpu_baseline"], result["parity"] = cpu_baseline(state, x_host[:n], probs)
@@ -216,14 +216,17 @@ def main():
         t0 = time.perf_counter()
         eng.enable_timing(False)
         from medaka_amd.torch_ext import Batch
-        model.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x_host)))
+        xb = Batch(counts_matrix=torch.from_numpy(x_host))
+        model.predict_on_batch(xb)                      # first call sizes the engine's staging buffers
+        t0 = time.perf_counter()
+        model.predict_on_batch(xb)
         result["pcie_inclusive_columns_per_s"] = cols_per_step / (time.perf_counter() - t0)
         # the same with the PCIe diet (SURVEY 8f f2 + f3): uint16 counts + uint32 depth in (24 B/column),
         # argmax class + its probability out (5 B/column)
         import numpy as np
         cnt = np.minimum(np.rint(x_host * 60.0), 65535).astype(np.uint16)
         dep = np.full(x_host.shape[:2], 60, dtype=np.uint32)
-        model.predict_on_counts(cnt[:8], dep[:8], decoded=True)
+        model.predict_on_counts(cnt, dep, decoded=True)
         t0 = time.perf_counter()
         model.predict_on_counts(cnt, dep, decoded=True)
         result["pcie_diet_columns_per_s"] = cols_per_step / (time.perf_counter() - t0)
