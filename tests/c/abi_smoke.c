@@ -1,0 +1,59 @@
+/* A plain-C host of the engine: what a non-Python embedder (or a cffi cdef) sees.  Builds with
+ *     gcc -std=c99 -I include tests/c/abi_smoke.c -L medaka_amd -lmedaka_amd -lm
+ * and, on a GPU box, runs a 2-window forward through mdk_gru_create / mdk_gru_forward and checks
+ * the softmax rows.  tests/test_host.py compiles and links it (no GPU needed for that),
+ * tests/test_parity_gpu.py runs it. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "medaka_amd.h"
+
+static float frand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+
+int main(void) {
+    const int I = 10, H = 128, G = 3 * H, B = 2, T = 300;
+    /* state_dict order: per layer and direction weight_ih, weight_hh, bias_ih, bias_hh; linear w, b */
+    const size_t sizes[18] = {(size_t)G * I, (size_t)G * H, G, G, (size_t)G * I, (size_t)G * H, G, G,
+                              (size_t)G * 2 * H, (size_t)G * H, G, G, (size_t)G * 2 * H, (size_t)G * H, G, G,
+                              (size_t)5 * 2 * H, 5};
+    const float *w[18];
+    unsigned seed = 7;
+    for (int i = 0; i < 18; ++i) {
+        float *p = (float *)malloc(sizes[i] * sizeof(float));
+        for (size_t j = 0; j < sizes[i]; ++j) p[j] = 0.2f * frand(&seed);
+        w[i] = p;
+    }
+    mdk_gru_desc desc = {I, H, 2, 1, 5, 1};
+    mdk_gru *m = NULL;
+    int n_dev = 0;
+    if (mdk_device_count(&n_dev) != MDK_OK || n_dev < 1) {
+        printf("no HIP device: %s\n", mdk_last_error());
+        return 77;   /* "skipped" */
+    }
+    if (mdk_gru_create(&desc, w, 18, 0, &m) != MDK_OK) {
+        printf("mdk_gru_create: %s\n", mdk_last_error());
+        return 1;
+    }
+    float *x = (float *)malloc((size_t)B * T * I * sizeof(float));
+    float *p = (float *)malloc((size_t)B * T * 5 * sizeof(float));
+    for (int i = 0; i < B * T * I; ++i) x[i] = frand(&seed) + 0.5f;
+    if (mdk_gru_forward(m, x, B, T, p) != MDK_OK) {
+        printf("mdk_gru_forward: %s\n", mdk_last_error());
+        return 1;
+    }
+    double worst = 0.0;
+    for (int r = 0; r < B * T; ++r) {
+        double s = 0.0;
+        for (int c = 0; c < 5; ++c) {
+            if (!(p[r * 5 + c] >= 0.0f && p[r * 5 + c] <= 1.0f)) { printf("bad probability\n"); return 1; }
+            s += p[r * 5 + c];
+        }
+        if (fabs(s - 1.0) > worst) worst = fabs(s - 1.0);
+    }
+    /* argument errors come back as codes + message, never as exit() */
+    if (mdk_gru_forward(m, NULL, B, T, p) != MDK_ERR_ARG) { printf("expected MDK_ERR_ARG\n"); return 1; }
+    mdk_gru_destroy(m);
+    printf("ok %s rows %d max|sum-1| %.2e\n", mdk_version(), B * T, worst);
+    return worst < 1e-5 ? 0 : 1;
+}

@@ -214,3 +214,22 @@ def test_integration_hook_keeps_reference_model_on_cpu(tmp_path):
     finally:
         integration.uninstall()
     assert ds.ModelStoreTGZ.load_model.__name__ == "load_model"
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    from medaka_amd import build as _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = _build.build()
+    exe = os.path.join(str(tmp_path), "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-L", os.path.dirname(so),
+                           "-lmedaka_amd", "-lm", "-Wl,-rpath," + os.path.dirname(so), "-o", exe])
+    return exe
+
+
+def test_c_host_compiles_and_links_against_the_header(tmp_path):
+    """include/medaka_amd.h is plain C99 and the library's entry points resolve from a C program
+    (the reference-side binding could equally be cffi, which medaka already uses for libmedaka)."""
+    exe = _build_c_host(tmp_path)
+    assert os.path.getsize(exe) > 0

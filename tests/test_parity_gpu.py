@@ -513,3 +513,12 @@ def test_wide_read_level_half_precision(B, P, D, wide_state):
     srt = np.sort(ref, -1)
     clear = (srt[..., -1] - srt[..., -2]) > 4e-2
     assert (out.argmax(-1) == ref.argmax(-1))[clear].all()
+
+
+def test_plain_c_host_runs(tmp_path):
+    """tests/c/abi_smoke.c: create / forward / error path / destroy from C, no Python in the loop."""
+    import subprocess
+    from test_host import _build_c_host
+    r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok ")
