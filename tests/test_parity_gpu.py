@@ -146,6 +146,18 @@ def test_overlapped_projection_agrees_bitwise(gold):
            oracle.c_gru_forward(x, weight_set(gold, "trained")), what="overlapped")
 
 
+def test_multi_pass_with_overlap_agrees_bitwise(gold):
+    """Passes share the side stream and the second gi buffer of the overlapped projection: results of
+    a 3-pass forward equal the single pass bit for bit (stream ordering keeps pass k+1's side-stream
+    GEMMs behind pass k's layer-1 recurrence)."""
+    x = synth.counts_windows(20, 2048, seed=67)
+    e = engine.GruEngine(weight_set(gold, "trained"))
+    one = e.forward_host(x)
+    e.set_option("max_rows_per_pass", 2048 * 8)
+    assert np.array_equal(e.forward_host(x), one)
+    e.close()
+
+
 def test_fused_and_unfused_layer0_agree(gold):
     x = synth.counts_windows(9, 400, seed=41)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
