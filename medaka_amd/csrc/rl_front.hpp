@@ -109,12 +109,15 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         n_reads_s = cnt;
     }
 
-    // conv1 row of this thread's channel
-    const int ci = tid & 127, rsel = tid >> 7;
-    float w1r[8];
+    // conv1 rows of this thread's two adjacent channels (one 4-byte LDS store per fp16 pair)
+    const int ci = 2 * (tid & 63), rsel = tid >> 6;
+    float w1r[2][8], b1v[2], a1v[2], c1v[2];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) w1r[f] = A.w1[ci * 8 + f];
-    const float b1v = A.b1[ci], a1v = A.a1[ci], c1v = A.c1[ci];
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) w1r[j][f] = A.w1[(ci + j) * 8 + f];
+        b1v[j] = A.b1[ci + j]; a1v[j] = A.a1[ci + j]; c1v[j] = A.c1[ci + j];
+    }
     // epilogue constants of this lane's conv2 / linear output columns: co = 32w + 16nt + n
     float b2v[2], a2v[2], c2v[2];
 #pragma unroll
@@ -156,17 +159,22 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         }
         __syncthreads();
         // ---- 1b. conv1 (k=1) + ReLU + BN1 -> fp16 hi/lo tile
-        for (int r = rsel; r < kRlRows; r += 2) {
-            float v = b1v;
+        for (int r = rsel; r < kRlRows; r += 4) {
+            half2_t hi2, lo2;
 #pragma unroll
-            for (int f = 0; f < 8; ++f) v = fmaf(w1r[f], feat[r][f], v);
-            v = fmaxf(v, 0.f);
-            v = fmaf(a1v, v, c1v);
-            if (!fvalid[r]) v = 0.f;                         // zero padding of conv2's input
-            _Float16 hi, lo;
-            split_f16(v * A.s1, hi, lo);
-            *reinterpret_cast<_Float16 *>(yhi + r * kRlRowBytes + ci * 2) = hi;
-            if constexpr (!HP) *reinterpret_cast<_Float16 *>(ylo + r * kRlRowBytes + ci * 2) = lo;
+            for (int j = 0; j < 2; ++j) {
+                float v = b1v[j];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) v = fmaf(w1r[j][f], feat[r][f], v);
+                v = fmaxf(v, 0.f);
+                v = fmaf(a1v[j], v, c1v[j]);
+                if (!fvalid[r]) v = 0.f;                     // zero padding of conv2's input
+                _Float16 hi, lo;
+                split_f16(v * A.s1, hi, lo);
+                hi2[j] = hi; lo2[j] = lo;
+            }
+            *reinterpret_cast<half2_t *>(yhi + r * kRlRowBytes + ci * 2) = hi2;
+            if constexpr (!HP) *reinterpret_cast<half2_t *>(ylo + r * kRlRowBytes + ci * 2) = lo2;
         }
         __syncthreads();
         // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks
