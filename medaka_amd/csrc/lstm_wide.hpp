@@ -12,16 +12,18 @@
 //     of lane (g, c) is exactly (i, f, g, o) of unit g for window c: the cell update needs no
 //     cross-lane traffic (fp32-parity mode: one DPP add joins the hi and lo columns of a window);
 //   * every step each member needs the WHOLE h_{t-1} (8 windows x 384 units).  Members publish their
-//     32 units as 8-byte {fp16 hi, fp16 lo, step tag} granules with one agent-scope relaxed atomic
-//     store each (= `global_store_dwordx2 sc1`, visible across CUs and XCDs without any fence),
-//     and gather all 3072 granules of the step with agent-scope atomic loads, re-polling a granule
-//     until its tag is the current step (MI355X_MICROARCH.md "Valid forms": 8-byte agent atomics on
-//     both sides; the data-tagged granule needs no separate flag).  Two parity buffers suffice:
-//     nobody can publish step t+2 before everybody has gathered step t (proof in DESIGN.md 4.5);
+//     32 units as 8-byte {fp16 hi, fp16 lo, step tag} granules, one 8-byte store each, and gather
+//     all 3072 granules of the step with 16-byte L1-bypassing (sc1) loads, re-polling until each
+//     8-byte half carries the current tag: the data-tagged granule needs no flag and no fence
+//     (MI355X_MICROARCH.md, hand-off form R2).  The stores are agent-scope atomics (write-through,
+//     valid across XCDs) unless the members verified at kernel start that they share one XCD, in
+//     which case plain stores that stay in that XCD's L2 are several times faster.  Two parity
+//     buffers suffice: nobody can publish step t+2 before everybody has gathered step t
+//     (DESIGN.md 4.5);
 //   * the gathered granules are written into the same LDS A-operand image the 128-unit kernel
 //     uses (rec_mfma.hpp), 12 k-steps long; rows = (window, hi|lo) as there;
-//   * two 8-window groups are interleaved per cluster so that one group's exchange latency is
-//     covered by the other group's MFMAs;
+//   * above 16 groups, two 8-window groups are interleaved per cluster so that one group's
+//     exchange latency is covered by the other group's MFMAs;
 //
 // Cluster members must be co-resident (they spin on each other): the grid is 8 XCDs x 2 clusters
 // x 12 members = 192 work-groups <= 256 CUs, one per CU, launched on an otherwise idle device;
