@@ -8,10 +8,10 @@
 //       W_ih of the first LSTM, so the host folds it into that projection (rl_api.hip)]
 //
 // One fused kernel, nothing per-read is ever written to HBM (the per-read activations would be
-// 512 B x B x D x P).  A work-group owns (window b, 64 positions) and walks the reads:
-//   1. features + conv1 + ReLU + BN for 80 positions (8 halo each side) straight into LDS as the
+// 512 B x B x D x P).  A work-group owns (window b, 96 positions) and walks the reads:
+//   1. features + conv1 + ReLU + BN for the tile's positions + 8 halo each side straight into LDS as the
 //      fp16 hi/lo A operand of conv2 (zero outside the window = the zero padding of conv2);
-//   2. conv2 as an implicit GEMM on the matrix cores: M = 64 positions, N = 128 channels,
+//   2. conv2 as an implicit GEMM on the matrix cores: M = 96 positions, N = 128 channels,
 //      K = 17 taps x 128 channels = 68 k-steps; the A fragment of tap tau is the same LDS tile
 //      read tau rows further down; W2 B-fragments stream from L2 (pre-packed);
 //   3. bias + ReLU + BN in registers, accumulated over the reads in registers (empty reads are
@@ -25,9 +25,15 @@
 
 namespace mdk {
 
-constexpr int kRlPos = 64;                       // positions per work-group
+#ifndef MDK_RL_MT
+#define MDK_RL_MT 6
+#endif
+constexpr int kRlMT = MDK_RL_MT;                 // 16-position M-tiles per wave; the W2 fragments of a k-step are loaded
+                                                 // once per kRlMT tiles.  Sweep (profiles/run_front_mt.sh, 100 x 10000 x 50):
+                                                 // 4: 77.3 / 38.9 ms (fp32 / half), 6: 76.0 / 37.2, 7: 75.9 / 47.9, 8: 91.8 / 46.6
+constexpr int kRlPos = 16 * kRlMT;               // positions per work-group
 constexpr int kRlHalo = 8;                       // (17 - 1) / 2
-constexpr int kRlRows = kRlPos + 2 * kRlHalo;    // 80 rows of conv1 output per tile
+constexpr int kRlRows = kRlPos + 2 * kRlHalo;    // rows of conv1 output per tile
 constexpr int kRlRowBytes = 272;                 // 128 channels x 2 B + 16 B pad (bank spread)
 constexpr int kRlTaps = 17;
 constexpr int kRlC = 128;                        // cnn_size == lstm_size == 128
@@ -89,7 +95,7 @@ struct RlFrontArgs {
 template <bool TILED, bool HP = false>
 __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];   // 43.5 KB
+    __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];
     __shared__ float feat[kRlRows][8];
     __shared__ int fvalid[kRlRows];
     __shared__ float emb_b[8][6], emb_s[3][6];
@@ -125,9 +131,9 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         const int co = 32 * w + 16 * nt + n;
         b2v[nt] = A.b2[co]; a2v[nt] = A.a2[co]; c2v[nt] = A.c2[co];
     }
-    floatx4 pool[4][2];
+    floatx4 pool[kRlMT][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < kRlMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) pool[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 
     for (int d = 0; d < A.Dp; ++d) {
         if (A.mask[(size_t)b * A.Dp + d] == 0) continue;   // uniform: empty reads contribute 0
-        // ---- 1a. features of the 80 positions
+        // ---- 1a. features of the tile's positions (+ halo)
         if (tid < kRlRows) {
             const int pp = p0 - kRlHalo + tid;
             const bool ok = pp >= 0 && pp < A.P;
@@ -178,9 +184,9 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         }
         __syncthreads();
         // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks
-        floatx4 acc[4][2];
+        floatx4 acc[kRlMT][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < kRlMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
         const half8 *wp = A.w2frag + (size_t)w * 4 * 64 + lane;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
                     if constexpr (!HP) bl[nt] = wk[(nt * 2 + 1) * 64];
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < kRlMT; ++mt) {
                     const int off = (16 * mt + n + tau) * kRlRowBytes + (32 * kb + 8 * g) * 2;
                     const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
                     half8 al;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
         __syncthreads();   // everybody is done reading the conv1 tile
         // ---- 3. bias + ReLU + BN2, accumulated over the reads in registers
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < kRlMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
     for (int nt = 0; nt < 2; ++nt) {
         const int co = 32 * w + 16 * nt + n;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < kRlMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = p0 + 16 * mt + 4 * g + r;
