@@ -431,12 +431,14 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const dim3 rgrid(n_wg, D);
 
     // projection GEMM of a layer over the 8-step strips [strip0, strip0 + n_strips)
-    auto launch_gemm = [&](const LayerDev &Lg, const float *src, float *gi_out, hipStream_t st, int strip0, int n_strips) {
+    auto launch_gemm = [&](const LayerDev &Lg, const float *src, float *gi_out, hipStream_t st, int strip0, int n_strips,
+                           const int *gcond = nullptr, int gwant = 0) {
         if (n_strips <= 0) return;
         const dim3 grid((unsigned)n_strips * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF>), grid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), st, \
-                       src, Lg.wih_frag, Lg.bias_gi, gi_out, n_tiles, T, D, Lg.inv_scale_gi, Lg.up_scale_rec, kActScale, strip0)
+                       src, Lg.wih_frag, Lg.bias_gi, gi_out, n_tiles, T, D, Lg.inv_scale_gi, Lg.up_scale_rec, kActScale, strip0, \
+                       gcond, gwant)
         if (D == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM
@@ -567,7 +569,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             size_t gspan = 0;
             for (int j = 0; j <= kOvChunks; ++j) {
                 rs0 = bounds[j]; rns = bounds[j + 1] - bounds[j];
-                if (fuse) { launch(true, cond, 0); launch_fallback(cond); }
+                if (fuse) launch(true, cond, 0);   // (the unfused twin runs once, after the chunks: see below)
                 else launch(false, nullptr, 0);
                 if (j == 0) continue;          // after T/2 steps no column has both directions yet
                 hipEvent_t ev = m->ov_ev[(l == 0 ? 0 : kOvChunks + 1) + j];
@@ -587,6 +589,14 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             hipEvent_t done = m->ov_ev[l == 0 ? 0 : kOvChunks + 1];
             HIP_TRY(hipEventRecord(done, m->side));
             HIP_TRY(hipStreamWaitEvent(s, done, 0));
+            if (l == 0 && fuse) {
+                // out-of-range input (flag raised by k_pack_x): the fused chunks were no-ops and the side
+                // stream projected stale activations.  The unfused twin now runs the whole layer and a
+                // conditional GEMM redoes the projection; both are empty launches otherwise.
+                rs0 = 0; rns = T;
+                launch_fallback(cond);
+                launch_gemm(m->layers[1], outp, m->gi2, s, 0, (T + kGemmSteps - 1) / kGemmSteps, cond, 1);
+            }
             if (l == 0) gemm_done = true;
             if (l == L - 1) head_done = true;
             m->last.rec_launches += kOvChunks;   // (+1 below)

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     float *__restrict__ gi,            // gi_t
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
     const float *__restrict__ out_scale_p, float a_scale,   // a_scale: power-of-two operand scale of act_in
-    int strip0)                                              // first 8-step strip of this launch
+    int strip0,                                              // first 8-step strip of this launch
+    const int *__restrict__ cond, int want)                  // run only if (*cond != 0) == want (cond may be null)
 {
+    if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -559,7 +559,7 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
         const dim3 ggrid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF, 4>), ggrid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
-                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale, 0)
+                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale, 0, (const int *)nullptr, 0)
         if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM
