@@ -177,6 +177,8 @@ int mdk_rl_set_precision(mdk_rl *m, int precision);
 int mdk_rl_set_normalise(mdk_rl *m, int normalise);
 /* Tuning / test knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8 | 16   lstm_size 128: recurrence work-group granularity
+ *   "overlap_gemm"         = 1 | 0                  lstm_size 384: next layer's projection on a side stream
+ *                                                   behind resumable recurrence chunks (P >= 1024)
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through
  *                                                   granules, even when a cluster shares one XCD
  *   "wide_groups_per_cluster" = 0 (auto) | 1 | 2     lstm_size 384: 8-window groups interleaved per cluster

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     float *__restrict__ out,            // [B*T][384]
     unsigned long long *exch,           // [clusters][2 groups][2 parity][8 windows][384 units] granules + headers, zeroed
     int *status,                        // [0] != 0: a cluster timed out
-    int B, int T, int reverse, float inv_scale, int n_clusters, int n_units, int force_wt, int poll_delay)
+    int B, int T, int reverse, float inv_scale, int n_clusters, int n_units, int force_wt, int poll_delay,
+    int s0, int ns, float *__restrict__ cstate)   // scan steps [s0, s0 + ns); s0 > 0 resumes from the h this
+                                                  // kernel stored at scan step s0 - 1 and the cell state in
+                                                  // cstate [B][384], which every launch leaves behind
 {
     __shared__ __attribute__((aligned(16))) unsigned char img[2][2][kWImgBytes];   // [group][parity]
     __shared__ int s_abort[2];
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     }
     const int rd_off = g * kHGroupStride + c * 16;
     const long tstep = reverse ? -1 : 1;
-    const int t_first = reverse ? (T - 1) : 0;
+    const int s_end = s0 + ns;
+    const int t_first = reverse ? (T - 1 - s0) : s0;
     const long gstride = tstep * (long)kWG4, ostride = tstep * (long)kWH;
 
 #pragma unroll
@@ -168,13 +172,45 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             if (!wok[x]) win = B - 1;
             gp[x] = gi + ((size_t)win * T + t_first) * kWG4 + col;
             op[x] = out + ((size_t)win * T + t_first) * kWH + unit;
-            cst[x] = 0.f;
+            cst[x] = (s0 > 0 && x < NGRP) ? cstate[(size_t)win * kWH + unit] : 0.f;
         }
         __syncthreads();                                  // previous pair's images are dead
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {   // h_0 = 0: the images the first step reads
-            uint32_t *z = reinterpret_cast<uint32_t *>(img[x][tag & 1]);
-            for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
+        for (int x = 0; x < 2; ++x) {   // the images the first step reads: h_0 = 0, or h of scan step s0 - 1
+            if (s0 == 0 || x >= NGRP) {
+                uint32_t *z = reinterpret_cast<uint32_t *>(img[x][tag & 1]);
+                for (int i = tid; i < kWImgBytes / 4; i += 512) z[i] = 0u;
+            } else {
+                const long tprev = (long)t_first - tstep;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int gidx = 2 * (tid + 512 * j);
+                    const int w = gidx / kWH, u = gidx % kWH;      // image rows 2w, 2w + 1; units u, u + 1
+                    auto row_of = [&](int wi) {
+                        int win = (NGRP * it + x) * GW + wi;
+                        if (win >= B) win = B - 1;
+                        return out + ((size_t)win * T + tprev) * kWH + u;
+                    };
+                    unsigned int r0, r1;
+                    if constexpr (HP) {      // rows = windows 2w, 2w + 1
+                        const float2 a = *reinterpret_cast<const float2 *>(row_of(2 * w));
+                        const float2 b2 = *reinterpret_cast<const float2 *>(row_of(2 * w + 1));
+                        r0 = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(a.x * kActScale)) |
+                             ((unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(a.y * kActScale)) << 16);
+                        r1 = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(b2.x * kActScale)) |
+                             ((unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(b2.y * kActScale)) << 16);
+                    } else {                 // rows = (window w, hi), (window w, lo)
+                        const float2 a = *reinterpret_cast<const float2 *>(row_of(w));
+                        _Float16 h0, l0, h1, l1;
+                        split_f16(a.x * kActScale, h0, l0);
+                        split_f16(a.y * kActScale, h1, l1);
+                        r0 = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                        r1 = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+                    }
+                    *reinterpret_cast<unsigned int *>(img[x][tag & 1] + g_off[j]) = r0;
+                    *reinterpret_cast<unsigned int *>(img[x][tag & 1] + g_off[j] + 16) = r1;
+                }
+            }
         }
         auto refill = [&](int x, int p, bool advance) {
             if constexpr (ABL & 1) gq[x][p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -186,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
 #pragma unroll
             for (int p = 0; p < PF; ++p) gq[x][p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int p = 0; p + 1 < PF; ++p) refill(x, p, p + 1 < T);
+            for (int p = 0; p + 1 < PF; ++p) refill(x, p, s0 + p + 1 < s_end);
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             if constexpr (NGRP == 2 && !(ABL & 4)) { if (do_gather) gather_issue(1 - x, gtag, v); }
             // gi prefetch is issued AFTER the gather loads: vmcnt retires in order, so this half-step's
             // gather wait does not include it and it has until the next half-step's to arrive
-            if constexpr (NGRP == 2) refill(x, (p + PF - 1) % PF, (step + PF) < T);    // the slot consumed one step ago
+            if constexpr (NGRP == 2) refill(x, (p + PF - 1) % PF, (step + PF) < s_end);    // the slot consumed one step ago
             __builtin_amdgcn_sched_barrier(0);
             floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -269,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             const float gg = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[2] + gv4.z) * c_tanh)), 1.0f);
             const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pre[3] + gv4.w) * c_sig));
             const float cv = __builtin_fmaf(fv, cst[x], iv * gg);
-            cst[x] = cv;
+            if (step < s_end) cst[x] = cv;        // (padding steps must not disturb the state a later launch resumes from)
             const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * (2.0f * L2E))), 1.0f);
             const float h = ov * tc;
             unsigned int payload;
@@ -296,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
                 }
             }
             if (lead) {
-                if constexpr (!(ABL & 8)) { if (step < T && wok[x]) op[x][0] = h; }
+                if constexpr (!(ABL & 8)) { if (step < s_end && wok[x]) op[x][0] = h; }
             }
             op[x] += ostride;
             __builtin_amdgcn_sched_barrier(0);
@@ -307,17 +343,17 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
                 gather_issue(x, gtag, v);
             }
             if constexpr (!(ABL & 4)) { if (do_gather) gather_finish(NGRP == 2 ? 1 - x : x, gtag, v); }
-            if constexpr (NGRP == 1) refill(x, (p + PF - 1) % PF, (step + PF) < T);
+            if constexpr (NGRP == 1) refill(x, (p + PF - 1) % PF, (step + PF) < s_end);
             lds_barrier();
         };
 
-        for (int step0 = 0; step0 < T; step0 += PF) {
+        for (int step0 = s0; step0 < s_end; step0 += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
-                const int step = step0 + p;      // steps >= T run too (stores masked): all members agree
+                const int step = step0 + p;      // steps >= s_end run too (stores masked): all members agree
                 ++tag;
                 if constexpr (NGRP == 2) {
-                    half_step(0, p, step, step > 0, tag - 1);
+                    half_step(0, p, step, step > s0, tag - 1);
                     half_step(1, p, step, true, tag);
                 } else {
                     half_step(0, p, step, true, tag);
@@ -338,6 +374,9 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             if (tid == 0) atomicExch(status, 1);
             return;
         }
+#pragma unroll
+        for (int x = 0; x < NGRP; ++x)
+            if (lead && wok[x]) cstate[(size_t)((NGRP * it + x) * GW + wl) * kWH + unit] = cst[x];
     }
 }
 
@@ -352,7 +391,8 @@ constexpr int kWGemmBlk = kWGemmRows * 16 + 16;   // one (k-step, lane-group) bl
 template <int KS, bool HP = false>   // HP: one fp16 product, hi image only
 __global__ __launch_bounds__(512, 1) void k_gemm_rows(
     const float *__restrict__ A, const half8 *__restrict__ wfrag, const float *__restrict__ bias,
-    float *__restrict__ out, long M, float a_scale, float alpha)
+    float *__restrict__ out, int T, int t_begin, int t_len, float a_scale, float alpha)   // rows (window blockIdx.y,
+                                                                                            // t in [t_begin, t_begin + t_len))
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int K = 32 * KS;
@@ -361,7 +401,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_rows(
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const long row0 = (long)blockIdx.x * kWGemmRows;
+    const long row0 = (long)blockIdx.y * T + t_begin + (long)blockIdx.x * kWGemmRows;
+    const long M = (long)blockIdx.y * T + t_begin + t_len;   // first row beyond this window's range
 
     for (int it = tid; it < kWGemmRows * 4 * KS; it += 512) {
         const int row = it / (4 * KS), k8 = it % (4 * KS);

@@ -65,6 +65,11 @@ struct mdk_rl {
     std::vector<WideLayer> wlayers;
     unsigned long long *exch = nullptr;
     int *status = nullptr;
+    float *gi2 = nullptr, *cstate = nullptr;   // second projection buffer / cell state between chunks
+    size_t cstate_cap = 0;
+    hipStream_t side = nullptr;               // next layer's projection under this layer's recurrence
+    std::vector<hipEvent_t> ov_ev;
+    int opt_overlap = 1;
     std::vector<LstmLayer> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace
@@ -92,7 +97,9 @@ extern "C" void mdk_rl_destroy(mdk_rl *m) {
         free_dev(L.inv_rec); free_dev(L.up_rec); free_dev(L.inv_gi);
     }
     for (auto &L : m->wlayers) { free_dev(L.whh_frag); free_dev(L.wih_frag); free_dev(L.bias); }
-    free_dev(m->exch); free_dev(m->status);
+    free_dev(m->exch); free_dev(m->status); free_dev(m->gi2); free_dev(m->cstate);
+    for (auto e : m->ov_ev) (void)hipEventDestroy(e);
+    if (m->side) (void)hipStreamDestroy(m->side);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -386,6 +393,8 @@ extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
         if (value != 0 && value != 4 && value != 8 && value != 16)
             return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
         m->opt_tile_windows = value;
+    } else if (!strcmp(key, "overlap_gemm")) {
+        m->opt_overlap = value ? 1 : 0;
     } else if (!strcmp(key, "wide_write_through")) {
         m->opt_force_wt = value ? 1 : 0;
     } else if (!strcmp(key, "wide_poll_delay")) {
@@ -430,10 +439,24 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     if (rows > m->ws_rows) {
         free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
         m->gi = m->act[0] = m->act[1] = nullptr; m->ws_rows = 0;
+        free_dev(m->gi2); m->gi2 = nullptr;
         HIP_TRY(hipMalloc((void **)&m->gi, rows * kWG4 * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->gi2, rows * kWG4 * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&m->act[0], rows * kWH * sizeof(float)));
         HIP_TRY(hipMalloc((void **)&m->act[1], rows * kWH * sizeof(float)));
         m->ws_rows = rows;
+    }
+    if ((size_t)B * kWH > m->cstate_cap) {
+        free_dev(m->cstate); m->cstate = nullptr; m->cstate_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->cstate, (size_t)B * kWH * sizeof(float)));
+        m->cstate_cap = (size_t)B * kWH;
+    }
+    if (!m->side) HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    constexpr int kChunks = 8;
+    while (m->ov_ev.size() < kChunks + 1) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->ov_ev.push_back(e);
     }
     HIP_TRY(hipMemsetAsync(m->mask, 0, (size_t)B * Dp * sizeof(int), s));
     hipLaunchKernelGGL(k_rl_mask, dim3((P + 255) / 256, B), dim3(256), 0, s, x_dev, P, Dp, F, m->mask);
@@ -455,43 +478,71 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     const int n_units = (n_groups + ngrp - 1) / ngrp;
     const int n_clusters = std::min(n_units, kWMaxClusters);
     const unsigned rec_grid = 8u * kWC * (unsigned)((n_clusters + 7) / 8);
-    const unsigned gemm_grid = (unsigned)((rows + kWGemmRows - 1) / kWGemmRows);
+    // The stack is uni-directional, so the next layer's projection of column t only needs this
+    // layer's h_t: each layer's recurrence runs as kChunks resumable launches and, behind every
+    // chunk, the next layer's k_gemm_rows for the columns just produced runs on a side stream, on the
+    // >= 64 CUs the clusters never occupy.  (The next recurrence scans the other way and still has
+    // to wait for the whole layer.)  Projections alternate between two gi buffers.
+    const bool ovl = m->opt_overlap && P >= 1024;
+    const int n_chunks = ovl ? kChunks : 1;
+    auto launch_gemm = [&](const WideLayer &Lg, const float *src, float *gi_out, hipStream_t st, int t_begin, int t_len) {
+        if (t_len <= 0) return;
+        const dim3 grid((unsigned)((t_len + kWGemmRows - 1) / kWGemmRows), (unsigned)B);
+#define MDK_WGEMM(KSV, HPF)                                                                              \
+    hipLaunchKernelGGL((k_gemm_rows<KSV, HPF>), grid, dim3(512), (size_t)2 * KSV * 4 * kWGemmBlk, st, src, \
+                       Lg.wih_frag, Lg.bias, gi_out, P, t_begin, t_len, Lg.a_scale, Lg.alpha)
+        if (Lg.KS == 4) { if (hp) MDK_WGEMM(4, true); else MDK_WGEMM(4, false); }
+        else { if (hp) MDK_WGEMM(12, true); else MDK_WGEMM(12, false); }
+#undef MDK_WGEMM
+    };
     const float *in = m->act[1];
+    launch_gemm(m->wlayers[0], in, m->gi, s, 0, P);
     for (size_t l = 0; l < m->wlayers.size(); ++l) {
         const WideLayer &Ld = m->wlayers[l];
         float *outp = m->act[l & 1];
-#define MDK_WGEMM(KSV, HPF)                                                                              \
-    hipLaunchKernelGGL((k_gemm_rows<KSV, HPF>), dim3(gemm_grid), dim3(512), (size_t)2 * KSV * 4 * kWGemmBlk, s, in, \
-                       Ld.wih_frag, Ld.bias, m->gi, (long)rows, Ld.a_scale, Ld.alpha)
-        if (Ld.KS == 4) { if (hp) MDK_WGEMM(4, true); else MDK_WGEMM(4, false); }
-        else { if (hp) MDK_WGEMM(12, true); else MDK_WGEMM(12, false); }
-#undef MDK_WGEMM
-        HIP_TRY(hipMemsetAsync(m->exch, 0, kWExchWords * sizeof(unsigned long long), s));
+        const float *gi_cur = (l & 1) ? m->gi2 : m->gi;
+        float *gi_next = (l & 1) ? m->gi : m->gi2;
+        const bool has_next = l + 1 < m->wlayers.size();
+        for (int j = 0; j < n_chunks; ++j) {
+            const int s0 = (int)((long)P * j / n_chunks) / 8 * 8;
+            const int s1 = (j + 1 == n_chunks) ? P : (int)((long)P * (j + 1) / n_chunks) / 8 * 8;
+            HIP_TRY(hipMemsetAsync(m->exch, 0, kWExchWords * sizeof(unsigned long long), s));
 #define MDK_WIDE_N(NG, HPF, ABLV)                                                                        \
-    hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, HPF, ABLV>), dim3(rec_grid), dim3(512), 0, s, m->gi, Ld.whh_frag, \
+    hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, HPF, ABLV>), dim3(rec_grid), dim3(512), 0, s, gi_cur, Ld.whh_frag, \
                        outp, m->exch, m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_units, m->opt_force_wt, \
-                       m->opt_poll_delay)
+                       m->opt_poll_delay, s0, s1 - s0, m->cstate)
 #define MDK_WIDE(ABLV)                                                                                   \
     do {                                                                                                 \
         if (hp) { if (ngrp == 2) MDK_WIDE_N(2, true, ABLV); else MDK_WIDE_N(1, true, ABLV); }            \
         else { if (ngrp == 2) MDK_WIDE_N(2, false, ABLV); else MDK_WIDE_N(1, false, ABLV); }             \
     } while (0)
 #ifdef MDK_WIDE_ABLATE   // timing experiments only (profiles/): MDK_WIDE_ABL selects a garbage-result variant
-        switch (getenv("MDK_WIDE_ABL") ? atoi(getenv("MDK_WIDE_ABL")) : 0) {
-            case 1: MDK_WIDE(1); break;
-            case 2: MDK_WIDE(2); break;
-            case 3: MDK_WIDE(3); break;
-            case 4: MDK_WIDE(4); break;
-            case 5: MDK_WIDE(5); break;
-            case 8: MDK_WIDE(8); break;
-            case 9: MDK_WIDE(9); break;
-            default: MDK_WIDE(0);
-        }
+            switch (getenv("MDK_WIDE_ABL") ? atoi(getenv("MDK_WIDE_ABL")) : 0) {
+                case 1: MDK_WIDE(1); break;
+                case 2: MDK_WIDE(2); break;
+                case 4: MDK_WIDE(4); break;
+                case 8: MDK_WIDE(8); break;
+                default: MDK_WIDE(0);
+            }
 #else
-        MDK_WIDE(0);
+            MDK_WIDE(0);
 #endif
 #undef MDK_WIDE
 #undef MDK_WIDE_N
+            if (!has_next) continue;
+            const int t_begin = Ld.reverse ? P - s1 : s0;
+            if (ovl) {
+                HIP_TRY(hipEventRecord(m->ov_ev[1 + j], s));
+                HIP_TRY(hipStreamWaitEvent(m->side, m->ov_ev[1 + j], 0));
+                launch_gemm(m->wlayers[l + 1], outp, gi_next, m->side, t_begin, s1 - s0);
+            } else {
+                launch_gemm(m->wlayers[l + 1], outp, gi_next, s, t_begin, s1 - s0);
+            }
+        }
+        if (has_next && ovl) {
+            HIP_TRY(hipEventRecord(m->ov_ev[0], m->side));
+            HIP_TRY(hipStreamWaitEvent(s, m->ov_ev[0], 0));
+        }
         in = outp;
     }
     {

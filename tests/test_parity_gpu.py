@@ -479,6 +479,22 @@ def test_wide_read_level_shapes_vs_oracle(B, P, D, wide_state):
     e.close()
 
 
+def test_wide_read_level_chunked_overlap_agrees_bitwise(wide_state):
+    """Windows of >= 1024 positions run every layer's recurrence as 8 resumable launches (h re-read
+    from the output, cell state from a side buffer) with the next layer's projection behind each
+    chunk on a side stream: same bits as the plain sequence, in both precisions."""
+    x = rl_oracle.synth_reads(19, 1100, 3, use_dwells=True, seed=91)
+    e = engine.RlEngine(wide_state, **WIDE_KW)
+    for half in (False, True):
+        e.set_precision(half)
+        e.set_option("overlap_gemm", 1)
+        a = e.forward_host(x)
+        e.set_option("overlap_gemm", 0)
+        b = e.forward_host(x)
+        assert np.array_equal(a, b), half
+    e.close()
+
+
 def test_wide_read_level_long_window_and_empty_window(wide_state):
     """A 2000-position window (4 x 2000 cluster exchanges) next to an all-empty window (NaN, as the
     reference's 0/0) in the same 8-window group: NaNs must stay in their own MFMA rows."""
