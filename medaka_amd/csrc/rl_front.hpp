@@ -30,7 +30,8 @@ namespace mdk {
 #endif
 constexpr int kRlMT = MDK_RL_MT;                 // 16-position M-tiles per wave; the W2 fragments of a k-step are loaded
                                                  // once per kRlMT tiles.  Sweep (profiles/run_front_mt.sh, 100 x 10000 x 50):
-                                                 // 4: 77.3 / 38.9 ms (fp32 / half), 6: 76.0 / 37.2, 7: 75.9 / 47.9, 8: 91.8 / 46.6
+                                                 // 4: 77.3 / 38.9 ms (fp32 / half), 6: 76.0 / 37.2, 7: 75.9 / 47.9, 8: 91.8 / 46.6;
+                                                 // forcing 3 work-groups per CU at 4 (<= 168 VGPRs) measured the same as 2
 constexpr int kRlPos = 16 * kRlMT;               // positions per work-group
 constexpr int kRlHalo = 8;                       // (17 - 1) / 2
 constexpr int kRlRows = kRlPos + 2 * kRlHalo;    // rows of conv1 output per tile
