@@ -249,6 +249,13 @@ def test_full_batch_properties(gold, engines):
     assert np.array_equal(out_p, out[perm])
     # and so does splitting it (ragged last tile: 200 = 96 + 104)
     assert np.array_equal(e.forward_host(x[:96]), out[:96])
+    # the side-stream overlap (default at this size) changes the schedule, not the arithmetic, and
+    # repeated runs are deterministic
+    assert np.array_equal(e.forward_host(x), out)
+    e.set_option("overlap_gemm", 0)
+    plain = e.forward_host(x)
+    e.set_option("overlap_gemm", 1)
+    assert np.array_equal(plain, out)
     # spot-check windows against the CPU oracle (seconds at this size)
     pick = [0, 77, 199]
     ref = oracle.c_gru_forward(x[pick], gold["weights_trained"])
