@@ -295,7 +295,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "fuse_l0")) {
         m->opt_fuse_l0 = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
-        m->opt_overlap = value ? 1 : 0;
+        m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
 
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
@@ -464,9 +464,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // Measured at B=200: 14.8 -> 13.5 ms per batch; the recurrence itself gets 9 % slower while the
     // GEMM runs (chip clock drops with the extra power draw -- padding its LDS so that no GEMM
     // work-group can share its CUs changed nothing), at B >= 1000 there are no idle CUs and no gain.
+    constexpr int kOvMaxWgs = 208;   // profiles/run_overlap_sweep.sh: +10 % at 128 work-groups, +5 % at 160, +-1 % at 200-256
     const bool overlap = m->opt_overlap && D == 2 && L >= 2 && !(abl != 0 && !hp && nq <= 2) &&
                          T >= 2048 && T % (2 * kGemmSteps) == 0 &&
-                         n_wg * D <= 160;   // only while the recurrence leaves a good part of the 256 CUs idle
+                         (n_wg * D <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
     const float *gi_l1 = m->gi;
     bool gemm_done = false;
     constexpr int kOvChunks = 6;   // (a finer, shrinking schedule measured no better: the GEMM is the longer leg)
