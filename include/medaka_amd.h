@@ -109,8 +109,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 /* Tuning knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8      recurrence work-group granularity
  *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
- *   "overlap_gemm"         = 1 | 0                  project layer 1 on a side stream under the tail of
- *                                                   layer 0's recurrence (bidirectional, T >= 2048, T % 16 == 0)
+ *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
+ *                                                   the tails of the recurrences (bidirectional, T >= 2048,
+ *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
  *                                                   larger batches run as equal passes
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
