@@ -423,7 +423,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const bool hp = (m->precision == MDK_PREC_FP16);
     const int n_win = n_tiles * kTileWin;
     int nq = 1;
-    while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > 256) nq *= 2;
+    // (profiles/run_tile_sweep.sh: at 256 work-groups of 4 windows the 8-window variant + overlap is
+    // already 3 % ahead, at 200 it is 3 % behind)
+    while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > 232) nq *= 2;
     if (m->opt_tile_windows == 4) nq = 1;
     if (m->opt_tile_windows == 8) nq = 2;
     if (m->opt_tile_windows == 16 && hp) nq = 4;
