@@ -5,11 +5,14 @@ medaka/common.py:429-453, gru.py:66), so N GPUs are N independent `medaka infere
 processes on disjoint `--regions`, joined by `medaka sequence out_0.hdf ... out_{N-1}.hdf`
 (reference README.md:294-330, stitch.py:202).  No collective is on the data path.
 
-This module only decides WHO takes WHICH region:
-  * whole contigs are assigned longest-first to the least loaded shard (LPT);
-  * contigs longer than a quarter of `total/n_shards` are first cut on multiples of `bam_chunk` with
-    `chunk_ovlp` bases of overlap, the same cut `prediction.predict` itself applies
-    (prediction.py:100-110 -> common.Region.split), so that stitch sees overlapping samples.
+This module only decides WHO takes WHICH region, and it cuts exactly where the reference cuts:
+`medaka inference` splits every region longer than `bam_chunk` into pieces of `bam_chunk` bases that
+start every `bam_chunk - chunk_ovlp` bases (prediction.py:100-110 -> common.Region.split with
+fixed_size=False, common.py:711-736).  `shard_regions` hands out THOSE pieces -- each is at most
+`bam_chunk` long, so the per-GPU process does not cut it again -- which makes the set of regions, hence
+of pileups, windows and samples, identical to a single-process run: the stitched consensus of the
+joined HDFs is the same by construction (tests/test_e2e_gpu.py checks it against the reference's
+own FASTQ).  Pieces are assigned longest-first to the least loaded shard (LPT), ties by input order.
 """
 from collections import namedtuple
 
@@ -22,53 +25,34 @@ def region_str(r):
 
 
 def split_region(region, chunk, overlap):
-    """Cut [start, end) into pieces of <= chunk bases overlapping by `overlap`
-    (semantics of reference common.Region.split, fixed-size chunks, last piece short)."""
+    """The pieces reference `Region.split(chunk, overlap, fixed_size=False)` yields, trailing short
+    piece included (it is narrower than chunk_len and ends in the reference's remainder pass)."""
     if chunk <= overlap:
         raise ValueError("chunk must exceed overlap")
-    out = []
-    pos = region.start
-    while True:
-        end = min(pos + chunk, region.end)
-        out.append(Region(region.ref_name, pos, end))
-        if end >= region.end:
-            break
-        pos = end - overlap
-    return out
+    if chunk >= region.end - region.start:
+        return [region]
+    return [Region(region.ref_name, s, min(s + chunk, region.end))
+            for s in range(region.start, region.end, chunk - overlap)]
 
 
 def shard_regions(contigs, n_shards, bam_chunk=1_000_000, chunk_ovlp=1000):
-    """contigs: iterable of (name, length) or Region.  Returns list[n_shards] of list[Region].
-
-    Deterministic: ties broken by input order.
-    """
+    """contigs: iterable of (name, length) or Region.  Returns list[n_shards] of list[Region], every
+    region one piece of the reference's own bam_chunk grid.  Deterministic."""
     if n_shards < 1:
         raise ValueError("n_shards must be >= 1")
-    regions = []
+    pieces = []
     for c in contigs:
         r = c if isinstance(c, Region) else Region(c[0], 0, int(c[1]))
-        if r.end > r.start:
-            regions.append(r)
-    total = sum(r.end - r.start for r in regions)
-    target = max(1, -(-total // n_shards))
-    # pieces of about a quarter of a shard keep the greedy packing within a few percent
-    per = max(bam_chunk, -(-(-(-target // 4)) // bam_chunk) * bam_chunk)
-    pieces = []
-    for r in regions:
-        if n_shards > 1 and (r.end - r.start) > per:
-            pieces.extend(split_region(r, per, chunk_ovlp))
-        else:
-            pieces.append(r)
+        if r.end > r.start:      # (a single process cuts its regions itself)
+            pieces.extend(split_region(r, bam_chunk, chunk_ovlp) if n_shards > 1 else [r])
     order = sorted(range(len(pieces)), key=lambda i: (-(pieces[i].end - pieces[i].start), i))
     shards = [[] for _ in range(n_shards)]
     load = [0] * n_shards
     for i in order:
         k = min(range(n_shards), key=lambda s: (load[s], s))
-        shards[k].append(pieces[i])
+        shards[k].append((i, pieces[i]))
         load[k] += pieces[i].end - pieces[i].start
-    for s in shards:
-        s.sort(key=lambda r: (r.ref_name, r.start))
-    return shards
+    return [[r for _, r in sorted(s)] for s in shards]     # input order inside a shard
 
 
 def shard_windows(n_windows, n_shards, rank):

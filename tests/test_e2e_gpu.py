@@ -1,0 +1,155 @@
+"""End-to-end parity (-m gpu), row a9 of SURVEY.md section 8: the engine sits where the reference's
+model sits -- inside `run_prediction`'s loop (prediction.py:44-52) -- and the samples it labels go
+through trim/stitch (stitch.py:33-83) to a FASTQ that must equal, byte for byte, the FASTQ the
+UNMODIFIED reference produced from the same pileups on PyTorch-CPU (tests/golden/stitch_cases.npz,
+oracle/make_golden_stitch.py).  The caller and stitcher used here are the restatements of
+oracle/stitch_oracle.py, pinned to the same goldens on the CPU (tests/test_oracle_stitch.py).
+
+  (i)   single process: identical record names and bases, qualities within the documented bound, identical loop shape;
+  (ii)  the same regions split across two shards by medaka_amd.sharding and the two stores joined
+        as `medaka sequence a.hdf b.hdf` does: identical FASTQ;
+  (iii) loop shape at production batch size: batches of 200 from a producer thread, a short last
+        batch, B = 1 remainders of arbitrary length; every row bit-identical to a single-window call;
+        other Python threads keep running while a forward is in flight (GIL released by ctypes)."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from medaka_amd import models, sharding
+from medaka_amd.torch_ext import Batch
+from oracle import stitch_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sgold():
+    return dict(np.load(os.path.join(GOLD, "stitch_cases.npz")))
+
+
+@pytest.fixture(scope="module")
+def model(gold):
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    return m.to("cuda").eval()
+
+
+class Spy:
+    def __init__(self, model):
+        self.model, self.shapes = model, []
+
+    def predict_on_batch(self, batch):
+        self.shapes.append(tuple(batch.counts_matrix.shape))
+        out = self.model.predict_on_batch(batch)
+        assert out.device.type == "cpu" and out.dtype == torch.float32
+        return out
+
+
+def _check_qualities(got, want):
+    """Phred characters are floor(-10 log10(1 - p)) (labels.py:388-402): not protected by the 1e-4
+    tolerance on p where p -> 1 ('Precision'), so they are held to: same length,
+    >= 97 % identical characters, never more than 3 apart (one fp32 ulp of p at Q60+ moves Q by 2)."""
+    a = np.frombuffer("".join(got).encode(), dtype=np.uint8).astype(int)
+    b = np.frombuffer("".join(want).encode(), dtype=np.uint8).astype(int)
+    assert a.shape == b.shape
+    same = float((a == b).mean())
+    print(f"quality characters identical: {same:.4%}, max |dQ| = {np.abs(a - b).max()}")
+    assert same >= 0.97 and np.abs(a - b).max() <= 3
+
+
+def _pileups(sources, spec):
+    jitter = spec.get("jitter", ())
+    return lambda r: so.pileups_in_region(sources, r, r.ref_name in jitter)
+
+
+@pytest.mark.parametrize("case", ["mini", "cfg1"])
+def test_stitched_fastq_identical_to_reference(sgold, model, case):
+    spec, sources = so.load_case(sgold, case)
+    spy = Spy(model)
+    store = so.predict(so.contig_regions(sources), _pileups(sources, spec), spy, Batch.collate,
+                       spec["chunk_len"], spec["chunk_ovlp"], spec["batch_size"], spec["bam_chunk"])
+    assert sorted(spy.shapes) == sorted(tuple(b) for b in sgold[f"{case}/batches"])
+    assert set(store) == set(sgold[f"{case}/written"].tolist())
+    lengths = {r.ref_name: r.end for r in so.contig_regions(sources)}
+    got, want = so.fastq(store, lengths), str(sgold[f"{case}/fastq"])
+    gl, wl = got.split("\n"), want.split("\n")
+    assert gl[0::4] == wl[0::4]                       # record names: contig breaks and coordinates
+    assert gl[1::4] == wl[1::4], "consensus bases differ from the reference's"
+    _check_qualities(gl[3::4], wl[3::4])
+
+
+@pytest.mark.parametrize("case", ["mini", "cfg1"])
+def test_sharded_run_joins_to_the_same_fastq(sgold, model, case):
+    """Two `medaka inference --regions <shard>` processes, then `medaka sequence a b` (README.md:309-330)."""
+    spec, sources = so.load_case(sgold, case)
+    contigs = so.contig_regions(sources)
+    shards = sharding.shard_regions([(r.ref_name, r.end) for r in contigs], 2, bam_chunk=spec["bam_chunk"],
+                                    chunk_ovlp=spec["chunk_ovlp"])
+    assert all(len(s) > 0 for s in shards)
+    stores = []
+    for regs in shards:
+        stores.append(so.predict([so.Region(*r) for r in regs], _pileups(sources, spec), model, Batch.collate,
+                                 spec["chunk_len"], spec["chunk_ovlp"], spec["batch_size"], spec["bam_chunk"]))
+    joined = {}
+    for st in stores:                                  # DataIndex over several files: first file wins a name
+        for k, v in st.items():
+            joined.setdefault(k, v)
+    assert set(joined) == set(sgold[f"{case}/written"].tolist())
+    assert len(stores[0]) > 0 and len(stores[1]) > 0
+    lengths = {r.ref_name: r.end for r in contigs}
+    got, want = so.fastq(joined, lengths).split("\n"), str(sgold[f"{case}/fastq"]).split("\n")
+    assert got[0::4] == want[0::4] and got[1::4] == want[1::4]
+    _check_qualities(got[3::4], want[3::4])
+
+
+def test_production_loop_shape_bitwise_and_gil(gold, model):
+    from medaka_amd import synth
+    chunk_len, ovlp, B = 1000, 200, 200
+    # 437 windows -> batches of 200, 200, 37; two narrow contigs -> B = 1 remainders of 777 and 13 columns
+    n_cols = (437 - 1) * (chunk_len - ovlp) + chunk_len
+    srcs = {}
+    for name, cols, seed in (("big", n_cols, 71), ("r1", 777, 72), ("r2", 13, 73)):
+        raw = synth.counts_windows(1, cols, depth=50, seed=seed, raw=True)
+        feats = (raw["counts"][0] / np.maximum(1, raw["depth"][0])[:, None]).astype(np.float32)
+        srcs[name] = [so.Pileup(name, feats, so.make_positions(raw["major"][0], raw["minor"][0]), None, raw["depth"][0])]
+    seen = []
+
+    def on_batch(loader, data, batch, probs):
+        p = probs.numpy()
+        seen.append(p.shape)
+        for i in sorted({0, len(data) // 2, len(data) - 1}):          # single-window calls: bit-identical rows
+            one = model.predict_on_batch(Batch.collate([data[i]])).numpy()
+            assert np.array_equal(one[0], p[i]), (p.shape, i)
+    store = so.predict(so.contig_regions(srcs), lambda r: so.pileups_in_region(srcs, r), model, Batch.collate,
+                       chunk_len, ovlp, B, 10**9, on_batch=on_batch)
+    assert seen[:3] == [(200, 1000, 5), (200, 1000, 5), (37, 1000, 5)]
+    assert sorted(seen[3:]) == [(1, 13, 5), (1, 777, 5)]
+    assert len(store) == 437 + 2
+    # GIL: a pure-Python ticker thread must keep its free-running pace while forwards are in flight
+    x = torch.from_numpy(synth.counts_windows(8, 10000, seed=5)).repeat(25, 1, 1)      # 200 x 10000
+    batch = Batch(counts_matrix=x)
+    model.predict_on_batch(batch)
+    ticks, stop = [0], threading.Event()
+
+    def ticker():
+        while not stop.is_set():
+            ticks[0] += 1
+    t = threading.Thread(target=ticker, daemon=True)
+    t.start()
+    time.sleep(0.2)
+    t0, a = time.perf_counter(), ticks[0]
+    time.sleep(0.3)
+    free_rate = (ticks[0] - a) / (time.perf_counter() - t0)
+    t0, a = time.perf_counter(), ticks[0]
+    for _ in range(10):
+        model.predict_on_batch(batch)
+    busy_rate = (ticks[0] - a) / (time.perf_counter() - t0)
+    stop.set()
+    t.join()
+    print(f"ticker: {free_rate:,.0f}/s free, {busy_rate:,.0f}/s during forwards")
+    assert busy_rate > 0.5 * free_rate

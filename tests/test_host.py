@@ -133,18 +133,22 @@ def test_batch_collate_counts_and_read_level():
         Batch.collate([S(np.zeros(4))])
 
 
-def test_sharding_lpt_and_split():
+def test_sharding_lpt_on_the_reference_grid():
     contigs = [("chr1", 250_000_000), ("chr2", 40_000_000), ("chr3", 30_000_000), ("chrM", 16_569)]
     shards = sharding.shard_regions(contigs, 8)
     assert len(shards) == 8 and all(len(s) > 0 for s in shards)
     load = [sum(r.end - r.start for r in s) for s in shards]
-    assert max(load) <= 1.25 * (sum(load) / 8)
-    # chr1 pieces overlap by chunk_ovlp and cover the contig, cut on multiples of bam_chunk
-    pieces = sorted([r for s in shards for r in s if r.ref_name == "chr1"], key=lambda r: r.start)
-    assert pieces[0].start == 0 and pieces[-1].end == 250_000_000
-    for a, b in zip(pieces, pieces[1:]):
-        assert a.end - b.start == 1000
-        assert (a.end - a.start) % 1_000_000 == 0
+    assert max(load) <= 1.02 * (sum(load) / 8)
+    # the union is exactly what ONE `medaka inference` would cut for itself (prediction.py:100-110 ->
+    # Region.split(bam_chunk, overlap=chunk_ovlp, fixed_size=False), restated in oracle/stitch_oracle.py
+    # and pinned there against the reference)
+    from oracle import stitch_oracle as so
+    want = []
+    for name, length in contigs:
+        want.extend(so.split_region(so.Region(name, 0, length), 1_000_000, 1000))
+    got = sorted((r for s in shards for r in s), key=lambda r: ([c[0] for c in contigs].index(r.ref_name), r.start))
+    assert [tuple(r) for r in got] == [tuple(r) for r in want]
+    assert all(r.end - r.start <= 1_000_000 for r in got)          # never cut again by the per-GPU process
     # whole small contigs are never cut
     assert sum(1 for s in shards for r in s if r.ref_name == "chrM") == 1
     one = sharding.shard_regions(contigs, 1)
