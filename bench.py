@@ -12,11 +12,15 @@ time of K steps.  Multi-GPU = independent replicas on disjoint window shards, no
 the data path (weak scaling: per-GPU batch fixed).
 
 Also reported on the same JSON line:
+  host_to_host  the rate SURVEY.md section 8d defines: host tensor in -> host tensor out through
+                `model.predict_on_batch` (reference models.py:303-313), 2 warm-ups + median of >= 5
+                timed batches, with the input/output copies streamed under the recurrences
   roofline      dominant kernel (k_rec_mfma, the GRU recurrence): algorithmic FLOP per launch
                 / hipEvent-measured launch duration vs the fp16 dense MFMA peak / 4 (the fp32-parity
                 split issues 4 fp16 MACs per algorithmic MAC); the native-fp32 fraction is kept beside it
-  cpu_baseline  the reference's own CPU path (PyTorch-CPU nn.GRU/Linear/softmax, restated in
-                oracle/oracle.py) timed on this box's host cores on a bounded sample
+  cpu_baseline  the reference's own CPU path (B in {10, 100, 200} x threads in
+                {1, 2, cpu_count}, 1 warm-up + median of 3, under a wall-clock cap) -- the unmodified
+                reference class when /root/reference is present, its PyTorch-CPU restatement otherwise
   parity        max |dp| and argmax identity of the engine vs that CPU result on the sample
 """
 import argparse
@@ -45,10 +49,11 @@ def parse():
     ap.add_argument("--chunk-len", type=int, default=10000, help="pileup columns per window")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--overlap", type=int, default=1, help="layer-1 projection GEMM under the tail of the layer-0 recurrence (0 off, 1 on)")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="windows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="wall-clock cap of the CPU baseline in seconds (0 = skip)")
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
+    ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
     return ap.parse_args()
 
 
@@ -56,39 +61,82 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(state, x_sample, probs_sample):
-    """Reference CPU path on a bounded sample; also the parity check of the same run.
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
-    PyTorch-CPU GRU scales poorly with threads (reference README.md:332-336 advises <= 2), so
-    a short sweep over thread counts is timed and the fastest is reported with its count."""
+
+def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
+    """BASELINE.md section 4 on this box's host cores, bounded by `budget_s` of wall clock.
+
+    Each (batch, threads) configuration runs in a child process (oracle/cpu_baseline.py: 1 short warm-up,
+    up to 3 timed passes, median) that is killed when its share of the budget is over; what finished
+    before a kill is kept, what did not fit is listed.  Plan: B in {10, 100, 200} x threads in
+    {1, 2, all cores}, cheapest first."""
+    import subprocess
+    import tempfile
     import numpy as np
-    import torch
-    from oracle import oracle
-    cores = os.cpu_count() or 1
-    m = oracle.make_torch_oracle(state)
-    cols = x_sample.shape[0] * x_sample.shape[1]
-    best, ref, sweep = None, None, {}
-    for nthreads in sorted({t for t in (2, 8, 32) if t <= cores} | {min(cores, 2)}):
-        torch.set_num_threads(nthreads)
-        m.predict(x_sample[:1, :500])                # warm-up
-        t0 = time.perf_counter()
-        out = m.predict(x_sample)
-        dt = time.perf_counter() - t0
-        sweep[nthreads] = cols / dt
-        log(f"cpu baseline: {nthreads} threads -> {cols / dt:,.0f} columns/s ({dt:.1f}s)")
-        if best is None or cols / dt > best[1]:
-            best = (nthreads, cols / dt)
-        ref = out.numpy() if ref is None else ref
-        if dt > 25:
-            break
-    base = {"value": best[1], "unit": "pileup columns/s", "cores": best[0], "kind": "port",
-            "host_cores_available": cores, "thread_sweep_columns_per_s": sweep,
-            "sample": f"{x_sample.shape[0]} windows x {x_sample.shape[1]} columns, PyTorch-CPU fp32 "
-                      f"nn.GRU+Linear+softmax (the ops of reference gru.py:66-71), one timed pass "
-                      f"per thread count, best reported"}
-    parity = {"max_abs_dp": float(np.abs(probs_sample - ref).max()),
-              "argmax_identical": bool((probs_sample.argmax(-1) == ref.argmax(-1)).all()),
-              "tolerance": 1e-4, "columns_checked": int(cols)}
+    cores = usable_cores()
+    B_all, T = x_host.shape[0], x_host.shape[1]
+    t_start = time.perf_counter()
+    left = lambda: budget_s - (time.perf_counter() - t_start)
+    thread_set = sorted({1, min(2, cores), cores})
+    plan = [(10, cores), (10, 2), (10, 1), (100, cores), (200, cores), (100, 2), (200, 2), (100, 1), (200, 1)]
+    plan = [(b, t) for b, t in plan if b <= B_all and t in thread_set]
+    table, skipped, ref, kind = [], [], None, "port"
+    est_rate = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        xin = os.path.join(tmp, "x.npy")
+        np.save(xin, x_host[:max(b for b, _ in plan)])
+        for b, nthreads in plan:
+            cols = b * T
+            rate = est_rate.get(nthreads)
+            if left() < 5 or (rate is not None and 1.2 * cols / rate > left()):
+                skipped.append({"batch": b, "threads": nthreads, "reason": "wall-clock cap"})
+                continue
+            outp = os.path.join(tmp, f"ref_{b}_{nthreads}.npy")
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--weights", weights_path,
+                   "--input", xin, "--batch", str(b), "--threads", str(nthreads), "--out", outp]
+            lines = []
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(5.0, min(left(), 0.5 * budget_s)))
+                lines = r.stdout.splitlines()
+            except subprocess.TimeoutExpired as e:
+                lines = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")).splitlines()
+            passes = [json.loads(l) for l in lines if l.startswith("{")]
+            if not passes:
+                skipped.append({"batch": b, "threads": nthreads, "reason": "no pass finished inside its time slice"})
+                est_rate[nthreads] = 1.0          # do not try larger batches with this thread count
+                continue
+            kind = passes[0]["kind"]
+            med = statistics.median(p["seconds"] for p in passes)
+            est_rate[nthreads] = cols / med
+            table.append({"batch": b, "threads": nthreads, "columns_per_s": cols / med, "median_s": med, "passes": len(passes)})
+            log(f"cpu baseline B={b} threads={nthreads}: {cols / med:,.0f} columns/s (median of {len(passes)}, {med:.2f}s)")
+            if os.path.exists(outp) and (ref is None or b > ref.shape[0]):
+                ref = np.load(outp)
+    if not table:
+        return ({"value": None, "unit": "pileup columns/s", "cores": 0, "kind": kind, "not_run": skipped,
+                 "sample": "no configuration finished inside the wall-clock cap"}, None)
+    best = max(table, key=lambda r: r["columns_per_s"])
+    base = {"value": best["columns_per_s"], "unit": "pileup columns/s", "cores": best["threads"], "kind": kind,
+            "host_cores_available": cores, "os_cpu_count": os.cpu_count(), "table": table, "not_run": skipped,
+            "wall_clock_cap_s": budget_s,
+            "sample": f"best of the BASELINE.md section-4 grid that fits {budget_s:.0f} s: B={best['batch']} x {T} columns, "
+                      f"{best['threads']} torch threads, fp32 PyTorch-CPU "
+                      + ("(unmodified reference GRUModel.predict_on_batch)" if kind == "reference" else
+                         "(nn.GRU+Linear+softmax, the ops of reference gru.py:66-71)")}
+    n = ref.shape[0]
+    parity = {"max_abs_dp": float(np.abs(probs_sample[:n] - ref).max()),
+              "argmax_identical": bool((probs_sample[:n].argmax(-1) == ref.argmax(-1)).all()),
+              "tolerance": 1e-4, "columns_checked": int(n * T)}
     return base, parity
 
 
@@ -158,12 +206,34 @@ def main():
     cols_per_step = B * T
     value = ranks.world * cols_per_step * args.steps / elapsed
 
+    # host tensor in -> host tensor out (what run_prediction's loop sees), every rank at once
+    eng.enable_timing(False)
+    from medaka_amd.torch_ext import Batch
+    xb = Batch(counts_matrix=torch.from_numpy(x_host))
+    h2h = []
+
+    def host_step():
+        t0 = time.perf_counter()
+        out_holder["p"] = model.predict_on_batch(xb)
+        h2h.append(time.perf_counter() - t0)
+    h_elapsed, _ = dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
+    h2h = h2h[2:]
+    h_med = ranks.max_over_ranks(statistics.median(h2h))
+    eng.set_option("stream_host", 0)
+    plain = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        model.predict_on_batch(xb)
+        plain.append(time.perf_counter() - t0)
+    eng.set_option("stream_host", 1)
+
     result = {
         "metric": "pileup columns/sec (consensus bi-GRU inference)",
         "value": value, "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if args.half else "f32",
+        "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
+                 "f32 (fp16 hi+lo split operands on the fp16 matrix pipe, fp32 accumulate; <= 1e-6 of fp32)",
         "data": "synthetic",
         "config": {"workload": f"r1041_e82_400bps_sup-architecture consensus (GRUModel 10->2x biGRU128->5), "
                                f"synthetic {args.depth}x pileup windows, batch {B} x {T} columns per GPU, "
@@ -172,6 +242,15 @@ def main():
                    "weights": "tests/golden/weights_trained.npz (reference-trained on synthetic data; "
                               "published model archives are git-LFS stubs offline)",
                    "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"},
+        "host_to_host": {
+            "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
+            "ms_per_batch_median": 1e3 * h_med, "timed_batches": len(h2h), "warmup": 2,
+            "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
+            "what": "model.predict_on_batch(Batch(counts_matrix=<pageable CPU tensor>)) -> CPU tensor, per rank, "
+                    "median over the timed batches, max over ranks; x streams in and probabilities stream out in "
+                    "time slabs under the recurrences (include/medaka_amd.h: mdk_gru_forward)",
+            "unstreamed_ms_per_batch": 1e3 * statistics.median(plain),
+        },
     }
     if ranks.rank == 0:
         rec_avg_ms = statistics.mean(rec_ms)
@@ -207,29 +286,22 @@ def main():
                                    "head": statistics.mean(head_ms[-args.steps:]),
                                    "device_total": statistics.mean(total_ms[-args.steps:])},
         }
-        if args.cpu_sample > 0 and ranks.world == 1:   # the CPU baseline is a single-GPU-run figure
-            n = min(args.cpu_sample, B)
-            probs = out_holder["y"][:n].cpu().numpy()
-            result["cpu_baseline"], result["parity"] = cpu_baseline(state, x_host[:n], probs)
-            result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
-        # host tensor in -> host tensor out (what predict_on_batch does), for DESIGN.md only
-        t0 = time.perf_counter()
-        eng.enable_timing(False)
-        from medaka_amd.torch_ext import Batch
-        xb = Batch(counts_matrix=torch.from_numpy(x_host))
-        model.predict_on_batch(xb)                      # first call sizes the engine's staging buffers
-        t0 = time.perf_counter()
-        model.predict_on_batch(xb)
-        result["pcie_inclusive_columns_per_s"] = cols_per_step / (time.perf_counter() - t0)
+        if args.cpu_budget > 0 and ranks.world == 1:   # the CPU baseline is a single-GPU-run figure
+            probs = out_holder["p"].numpy()
+            result["cpu_baseline"], result["parity"] = cpu_baseline(
+                os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), x_host, probs, args.cpu_budget)
+            if result["cpu_baseline"]["value"]:
+                result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         # the same with the PCIe diet (SURVEY 8f f2 + f3): uint16 counts + uint32 depth in (24 B/column),
         # argmax class + its probability out (5 B/column)
-        import numpy as np
         cnt = np.minimum(np.rint(x_host * 60.0), 65535).astype(np.uint16)
         dep = np.full(x_host.shape[:2], 60, dtype=np.uint32)
-        model.predict_on_counts(cnt, dep, decoded=True)
-        t0 = time.perf_counter()
-        model.predict_on_counts(cnt, dep, decoded=True)
-        result["pcie_diet_columns_per_s"] = cols_per_step / (time.perf_counter() - t0)
+        diet = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            model.predict_on_counts(cnt, dep, decoded=True)
+            diet.append(time.perf_counter() - t0)
+        result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[1:])
         print(json.dumps(result), flush=True)
     ranks.close()
 

@@ -87,7 +87,9 @@ int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weights, int n_
  * x_host: B x T x num_features contiguous fp32 (host);  probs_host: B x T x num_classes fp32
  * (host), fully overwritten.  Synchronous: returns when probs_host is complete.  B, T >= 0;
  * any B (last batch is short, medaka/common.py:903-916) and any T (the un-chunked B=1 second
- * pass, medaka/prediction.py:196-209).
+ * pass, medaka/prediction.py:196-209).  Internally x is copied in and the probabilities out in time
+ * slabs while the recurrences run (bidirectional models, T >= 2048, T % 16 == 0; otherwise one copy
+ * each side); pageable and page-locked buffers are both accepted.
  */
 int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host);
 
@@ -112,6 +114,10 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
+ *   "split_sync"           = 1 | 0                  recurrence: per-wave flags + half-K waits (1) or one
+ *                                                   barrier per step (0)
+ *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
+ *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
  *                                                   larger batches run as equal passes
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
@@ -178,6 +184,7 @@ int mdk_rl_set_precision(mdk_rl *m, int precision);
 int mdk_rl_set_normalise(mdk_rl *m, int normalise);
 /* Tuning / test knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8 | 16   lstm_size 128: recurrence work-group granularity
+ *   "split_sync"           = 1 | 0                  lstm_size 128: recurrence with per-wave flags + half-K waits
  *   "overlap_gemm"         = 1 | 0                  lstm_size 384: next layer's projection on a side stream
  *                                                   behind resumable recurrence chunks (P >= 1024)
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through
@@ -214,6 +221,12 @@ int mdk_device_count(int *count);
 int mdk_device_name(int device, char *buf, size_t buflen);
 int mdk_dev_alloc(int device, size_t bytes, void **ptr);
 int mdk_dev_free(int device, void *ptr);
+/* Page-locked host buffers (hipHostMalloc): as x_host / probs_host of the forward entry points they are
+ * copied by DMA directly and never page-fault inside the call.  Any host memory is accepted there;
+ * these are for callers that own their buffers (the Python layer takes its output tensors from
+ * torch's pinned allocator instead). */
+int mdk_host_alloc(size_t bytes, void **ptr);
+int mdk_host_free(void *ptr);
 int mdk_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
 int mdk_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int mdk_device_synchronize(int device);

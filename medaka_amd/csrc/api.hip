@@ -75,10 +75,15 @@ struct mdk_gru {
     size_t aux_cap = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;              // projection GEMM of layer 1 under the tail of layer 0
-    std::vector<hipEvent_t> ov_ev;
+    hipStream_t copy_in = nullptr;           // host path: time slabs of x, host -> device, ahead of the layer-0 recurrence
+    hipStream_t copy_out = nullptr;          // host path: finished probability columns, device -> host
+    std::vector<hipEvent_t> ov_ev;           // event pool of one forward pass (no timing)
+    size_t ov_next = 0;
     float *gi2 = nullptr;                    // its own gi buffer (layer 0's fallback may still read gi)
     size_t gi2_rows = 0;
     int opt_overlap = 1;
+    int opt_split_sync = 1;                  // recurrence: per-wave flags and half-K waits instead of one barrier per step
+    int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
     // timing
     bool timing = false;
     mdk_gru_timing last{};
@@ -99,6 +104,8 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->side) (void)hipStreamDestroy(m->side);
+    if (m->copy_in) (void)hipStreamDestroy(m->copy_in);
+    if (m->copy_out) (void)hipStreamDestroy(m->copy_out);
     delete m;
 }
 
@@ -128,7 +135,9 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
 
     for (int l = 0; l < L; ++l) {
@@ -296,6 +305,10 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_fuse_l0 = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
+    } else if (!strcmp(key, "split_sync")) {
+        m->opt_split_sync = value ? 1 : 0;
+    } else if (!strcmp(key, "stream_host")) {
+        m->opt_stream_host = value ? 1 : 0;
 
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
@@ -372,8 +385,33 @@ struct EvTimer {
 
 enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
 
+// Host path of mdk_gru_forward (reference TorchModel.predict_on_batch, models.py:303-313: host tensor in,
+// host tensor out): x arrives and the probabilities leave in TIME SLABS while the recurrences run.
+//   in : scan step s of a bidirectional layer needs column s (forward) and T-1-s (reverse), so the slabs
+//        come from both ends towards the middle -- [0,T/16)+[15T/16,T) first, doubling -- as strided 2-D
+//        copies (one row of slab columns per window) into the natural (B,T,F) device layout; layer 0's
+//        recurrence is cut at the same boundaries and each piece waits only for its own slabs;
+//   out: the classifier head already runs in column chunks under the tail of the last recurrence; each
+//        chunk is copied out as soon as it exists (again 2-D: nt columns x nb windows).
+// 80 MB in + 40 MB out per 200 x 10000 batch cost 2.1 ms of PCIe time (profiles/r2_host_path_probe.txt);
+// what stays exposed is the first slab pair (10 MB) and the last head chunk.
+struct HostIO {
+    const float *x_host = nullptr;   // (nb, T, F) of this pass, or null: x is already on the device
+    float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
+};
+
+static int pool_event(mdk_gru *m, hipEvent_t *out) {
+    if (m->ov_next == m->ov_ev.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->ov_ev.push_back(e);
+    }
+    *out = m->ov_ev[m->ov_next++];
+    return MDK_OK;
+}
+
 static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs, hipStream_t s,
-                        EvTimer &tm) {
+                        EvTimer &tm, const HostIO *io) {
     const int D = m->D, L = m->desc.num_layers;
     const long M = (long)nb * T;
     const int reverse_mask = (D == 2) ? 2 : 0;
@@ -381,7 +419,12 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const int n_tiles = (nb + kTileWin - 1) / kTileWin;
     int rc;
     const float *in = x;
+    const bool io_in = io && io->x_host, io_out = io && io->p_host;
+    const size_t x_bytes = (size_t)M * m->desc.num_features * sizeof(float);
+    const size_t p_bytes = (size_t)M * m->desc.num_classes * sizeof(float);
+    m->ov_next = 0;
     if (exact) {
+        if (io_in) HIP_TRY(hipMemcpyAsync(const_cast<float *>(x), io->x_host, x_bytes, hipMemcpyHostToDevice, s));
         // natural [window][t][f] layouts, plain fp32 kernels
         const size_t gi_dir_stride = (size_t)M * kG;
         const int out_stride = D * kH;
@@ -409,6 +452,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                                m->lin_b, probs, M, m->desc.normalise);
         if ((rc = tm.end())) return rc;
         HIP_TRY(hipGetLastError());
+        if (io_out) HIP_TRY(hipMemcpyAsync(io->p_host, probs, p_bytes, hipMemcpyDeviceToHost, s));
         return MDK_OK;
     }
 
@@ -467,9 +511,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // GEMM runs (chip clock drops with the extra power draw -- padding its LDS so that no GEMM
     // work-group can share its CUs changed nothing), at B >= 1000 there are no idle CUs and no gain.
     constexpr int kOvMaxWgs = 208;   // profiles/run_overlap_sweep.sh: +10 % at 128 work-groups, +5 % at 160, +-1 % at 200-256
-    const bool overlap = m->opt_overlap && D == 2 && L >= 2 && !(abl != 0 && !hp && nq <= 2) &&
-                         T >= 2048 && T % (2 * kGemmSteps) == 0 &&
+    const bool ablated = (abl != 0 && !hp && nq <= 2);
+    const bool can_chunk = D == 2 && !ablated && T >= 2048 && T % (2 * kGemmSteps) == 0;
+    const bool overlap = m->opt_overlap && can_chunk && L >= 2 &&
                          (n_wg * D <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
+    const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
+    const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
+    const bool stream_out = io_out && can_chunk && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
+    if (io_in && !stream_in)
+        HIP_TRY(hipMemcpyAsync(const_cast<float *>(x), io->x_host, x_bytes, hipMemcpyHostToDevice, s));
     const float *gi_l1 = m->gi;
     bool gemm_done = false;
     constexpr int kOvChunks = 6;   // (a finer, shrinking schedule measured no better: the GEMM is the longer leg)
@@ -480,22 +530,37 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             HIP_TRY(hipMalloc((void **)&m->gi2, (size_t)D * rows * kG * sizeof(float)));
             m->gi2_rows = rows;
         }
-        while (m->ov_ev.size() < 2 * (kOvChunks + 1)) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->ov_ev.push_back(e);
-        }
         gi_l1 = m->gi2;
     }
+    const int F = m->desc.num_features, C = m->desc.num_classes;
+    // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
+    auto copy_in_cols = [&](int t0, int nt) -> int {
+        if (nt <= 0) return MDK_OK;
+        HIP_TRY(hipMemcpy2DAsync(const_cast<float *>(x) + (size_t)t0 * F, (size_t)T * F * sizeof(float),
+                                 io->x_host + (size_t)t0 * F, (size_t)T * F * sizeof(float),
+                                 (size_t)nt * F * sizeof(float), (size_t)nb, hipMemcpyHostToDevice, m->copy_in));
+        return MDK_OK;
+    };
+    struct OutRange { hipEvent_t ready; int t0, nt; };
+    std::vector<OutRange> out_ranges;   // head chunks to copy out; issued after every launch is enqueued, because a
+                                        // copy into pageable memory may block the calling thread until it is done
+    auto pack_cols = [&](const LayerDev &Lp, const float *src, int t0, int nt) {
+        if (nt <= 0) return;
+        const size_t need = (size_t)n_wg * nt * 64;
+        hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, src, m->xfrag, nb, T,
+                           Lp.K, nq, hp ? 1 : 0, n_wg, Lp.x_scale, m->oor_flag, t0, nt);
+    };
 
     for (int l = 0; l < L; ++l) {
         const LayerDev &Ld = m->layers[l];
         float *outp = m->act[l & 1];
-        const bool ablated = (abl != 0 && !hp && nq <= 2);
         int rs0 = 0, rns = T;
         const float *gi_src = (l == 1 && gemm_done) ? gi_l1 : m->gi;
-        const bool fuse = (l == 0) && m->opt_fuse_l0 && Ld.wx_frag != nullptr && !ablated;
+        const bool fuse = (l == 0) && fuse0;
         const int *cond = fuse ? m->oor_flag : nullptr;
+        const bool slabs = stream_in && l == 0;                    // this layer's recurrence waits for x slab by slab
+        const bool side_gemm = overlap && l == 0;                  // layer 1's projection behind this layer's chunks
+        const bool side_head = (overlap || stream_out) && l == L - 1 && L >= 2;   // classifier head behind the chunks
         if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
         if (fuse) {
             const size_t need = (size_t)n_wg * T * 64;
@@ -505,25 +570,30 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 m->xfrag_cap = need;
             }
             HIP_TRY(hipMemsetAsync(m->oor_flag, 0, sizeof(int), s));
-            hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, in, m->xfrag, nb, T,
-                               Ld.K, nq, hp ? 1 : 0, n_wg, Ld.x_scale, m->oor_flag);
+            if (!slabs) pack_cols(Ld, in, 0, T);
         }
-        if (l == 0) {
-            // unfused layer-0 projection: the only path without fusion, the on-device fallback
-            // (input beyond fp16 range) with it
+        // unfused layer-0 projection: the only path without fusion, the on-device fallback (input beyond
+        // fp16 range) with it.  It reads all of x, so with slabs it is enqueued after the last of them.
+        auto launch_gi_small = [&]() {
             const int tpb = 128;
             hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, in,
                                Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec, cond, 1);
+        };
+        if (l == 0) {
+            if (!slabs) launch_gi_small();
         } else {
             if (!(l == 1 && gemm_done)) launch_gemm(Ld, in, m->gi, s, 0, (T + kGemmSteps - 1) / kGemmSteps);
         }
         if ((rc = tm.end())) return rc;
         size_t rspan = 0;
         if ((rc = tm.begin(SLOT_REC0 + l, (hipStream_t)-1, &rspan))) return rc;
-#define MDK_LAUNCH_REC(NQV, XIN, HPF, A, CND, WANT)                                                \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, A>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+#define MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, CND, WANT)                                        \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, A, SPLV>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
                        Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
                        reverse_mask, CND, WANT, rs0, rns)
+#define MDK_LAUNCH_REC(NQV, XIN, HPF, A, CND, WANT)                                                \
+    do { if ((A) == 0 && m->opt_split_sync) MDK_LAUNCH_REC_S(NQV, XIN, HPF, 0, true, CND, WANT);   \
+         else MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, false, CND, WANT); } while (0)
         // production instantiations
         auto launch = [&](bool xin, const int *cnd, int want) {
             if (hp) {
@@ -538,7 +608,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         // the fallback twin is instantiated with a different ring depth only so that profilers
         // show it under its own symbol (its launches are empty unless the range flag is raised)
 #define MDK_LAUNCH_FB(NQV, HPF)                                                                    \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF - 1, NQV, false, HPF, 0>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF - 1, NQV, false, HPF, 0, 0, true>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
                        Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
                        reverse_mask, cnd, 1, rs0, rns)
         auto launch_fallback = [&](const int *cnd) {
@@ -560,49 +630,79 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
             }
 #undef MDK_ABL_CASE
-        } else if (overlap && (l == 0 || l == L - 1)) {
-            // first half in one launch, second half in chunks; behind each chunk, on the side stream,
-            // what the newly complete columns [T-s', T-s) + [s, s') feed: layer 1's projection (l = 0)
-            // or the classifier head (last layer)
-            int bounds[kOvChunks + 2];
-            bounds[0] = 0;
-            for (int j = 0; j <= kOvChunks; ++j)
-                bounds[j + 1] = T / 2 + (int)((long)(T / 2) * j / kOvChunks) / kGemmSteps * kGemmSteps;
-            bounds[kOvChunks + 1] = T;
+        } else if (slabs || side_gemm || side_head) {
+            // The scan is cut into phases [ph[p], ph[p+1]).  First half: one phase, or -- when x is still
+            // arriving -- four that double in length, each behind the copy of its two slabs.  Second half:
+            // one phase, or kOvChunks with, behind each on the side stream, what the newly complete columns
+            // [T-s', T-s) + [s, s') feed: layer 1's projection (l = 0) or the classifier head (last layer).
+            std::vector<int> ph{0};
+            if (slabs) for (int sh = 4; sh >= 2; --sh) ph.push_back((T >> sh) / kGemmSteps * kGemmSteps);
+            ph.push_back(T / 2);
+            const int n_first = (int)ph.size() - 1;
+            if (side_gemm || side_head)
+                for (int j = 1; j < kOvChunks; ++j) ph.push_back(T / 2 + (int)((long)(T / 2) * j / kOvChunks) / kGemmSteps * kGemmSteps);
+            ph.push_back(T);
+            const int n_ph = (int)ph.size() - 1;
             size_t gspan = 0;
-            for (int j = 0; j <= kOvChunks; ++j) {
-                rs0 = bounds[j]; rns = bounds[j + 1] - bounds[j];
-                if (fuse) launch(true, cond, 0);   // (the unfused twin runs once, after the chunks: see below)
+            bool gspan_open = false;
+            for (int p = 0; p < n_ph; ++p) {
+                rs0 = ph[p]; rns = ph[p + 1] - ph[p];
+                if (slabs && p < n_first) {
+                    // columns [rs0, rs0+rns) and their mirror [T-rs0-rns, T-rs0); the last pair is adjacent
+                    const int lo = rs0, hi = T - rs0 - rns;
+                    if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
+                    else { if ((rc = copy_in_cols(lo, rns)) || (rc = copy_in_cols(hi, rns))) return rc; }
+                    hipEvent_t ev;
+                    if ((rc = pool_event(m, &ev))) return rc;
+                    HIP_TRY(hipEventRecord(ev, m->copy_in));
+                    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+                    if (fuse) { pack_cols(Ld, in, lo, rns); pack_cols(Ld, in, hi, rns); }
+                }
+                if (fuse) launch(true, cond, 0);   // (the unfused twin runs once, after the phases: see below)
                 else launch(false, nullptr, 0);
-                if (j == 0) continue;          // after T/2 steps no column has both directions yet
-                hipEvent_t ev = m->ov_ev[(l == 0 ? 0 : kOvChunks + 1) + j];
+                m->last.rec_launches++;
+                if (p < n_first || !(side_gemm || side_head)) continue;   // before T/2 steps no column has both directions
+                hipEvent_t ev;
+                if ((rc = pool_event(m, &ev))) return rc;
                 HIP_TRY(hipEventRecord(ev, s));
                 HIP_TRY(hipStreamWaitEvent(m->side, ev, 0));
-                const int lo0 = T - bounds[j + 1], hi0 = bounds[j], len = bounds[j + 1] - bounds[j];
-                if (l == 0) {
-                    if (j == 1 && (rc = tm.begin(SLOT_GI0 + 1, m->side, &gspan))) return rc;
+                const int lo0 = T - ph[p + 1], hi0 = ph[p], len = ph[p + 1] - ph[p];
+                if (side_gemm) {
+                    if (!gspan_open) { if ((rc = tm.begin(SLOT_GI0 + 1, m->side, &gspan))) return rc; gspan_open = true; }
                     launch_gemm(m->layers[1], outp, m->gi2, m->side, lo0 / kGemmSteps, len / kGemmSteps);
                     launch_gemm(m->layers[1], outp, m->gi2, m->side, hi0 / kGemmSteps, len / kGemmSteps);
                 } else {
                     launch_head(outp, m->side, lo0, len);
                     launch_head(outp, m->side, hi0, len);
+                    if (stream_out) {
+                        hipEvent_t hv;
+                        if ((rc = pool_event(m, &hv))) return rc;
+                        HIP_TRY(hipEventRecord(hv, m->side));
+                        if (lo0 + len == hi0) out_ranges.push_back({hv, lo0, 2 * len});
+                        else { out_ranges.push_back({hv, lo0, len}); out_ranges.push_back({hv, hi0, len}); }
+                    }
                 }
             }
-            if (l == 0 && (rc = tm.end_at(gspan))) return rc;
-            hipEvent_t done = m->ov_ev[l == 0 ? 0 : kOvChunks + 1];
-            HIP_TRY(hipEventRecord(done, m->side));
-            HIP_TRY(hipStreamWaitEvent(s, done, 0));
-            if (l == 0 && fuse) {
-                // out-of-range input (flag raised by k_pack_x): the fused chunks were no-ops and the side
-                // stream projected stale activations.  The unfused twin now runs the whole layer and a
-                // conditional GEMM redoes the projection; both are empty launches otherwise.
-                rs0 = 0; rns = T;
-                launch_fallback(cond);
-                launch_gemm(m->layers[1], outp, m->gi2, s, 0, (T + kGemmSteps - 1) / kGemmSteps, cond, 1);
+            m->last.rec_launches--;   // (+1 below)
+            if (gspan_open && (rc = tm.end_at(gspan))) return rc;
+            if (side_gemm || side_head) {
+                hipEvent_t done;
+                if ((rc = pool_event(m, &done))) return rc;
+                HIP_TRY(hipEventRecord(done, m->side));
+                HIP_TRY(hipStreamWaitEvent(s, done, 0));
             }
-            if (l == 0) gemm_done = true;
-            if (l == L - 1) head_done = true;
-            m->last.rec_launches += kOvChunks;   // (+1 below)
+            if (l == 0 && fuse) {
+                // out-of-range input (flag raised by k_pack_x): the fused phases were no-ops and the side
+                // stream projected stale activations.  The unfused twin now runs the whole layer and a
+                // conditional GEMM redoes the projection; all are empty launches otherwise.
+                rs0 = 0; rns = T;
+                if (slabs) launch_gi_small();
+                launch_fallback(cond);
+                if (side_gemm)
+                    launch_gemm(m->layers[1], outp, m->gi2, s, 0, (T + kGemmSteps - 1) / kGemmSteps, cond, 1);
+            }
+            if (side_gemm) gemm_done = true;
+            if (side_head) head_done = true;
         } else if (fuse) {
             launch(true, cond, 0);     // fused: runs unless the range flag is up
             launch_fallback(cond);     // unfused twin: runs only on the flag
@@ -610,6 +710,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             launch(false, nullptr, 0);
         }
 #undef MDK_LAUNCH_REC
+#undef MDK_LAUNCH_REC_S
         if ((rc = tm.end_at(rspan))) return rc;
         m->last.rec_launches++;
         in = outp;
@@ -618,6 +719,24 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if (!head_done) launch_head(in, s, 0, T);
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
+    if (io_out) {
+        if (!head_done) {
+            HIP_TRY(hipMemcpyAsync(io->p_host, probs, p_bytes, hipMemcpyDeviceToHost, s));
+        } else {
+            // every kernel of the pass is enqueued: now the copies, each behind its head chunk
+            for (const OutRange &r : out_ranges) {
+                HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
+                HIP_TRY(hipMemcpy2DAsync(io->p_host + (size_t)r.t0 * C, (size_t)T * C * sizeof(float),
+                                         probs + (size_t)r.t0 * C, (size_t)T * C * sizeof(float),
+                                         (size_t)r.nt * C * sizeof(float), (size_t)nb, hipMemcpyDeviceToHost,
+                                         m->copy_out));
+            }
+            hipEvent_t done;
+            if ((rc = pool_event(m, &done))) return rc;
+            HIP_TRY(hipEventRecord(done, m->copy_out));
+            HIP_TRY(hipStreamWaitEvent(s, done, 0));   // a synchronize on `s` then covers the copies
+        }
+    }
     return MDK_OK;
 }
 
@@ -640,16 +759,11 @@ static int finish_timing(mdk_gru *m, EvTimer &tm, hipStream_t s) {
     return MDK_OK;
 }
 
-extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
-                                   void *stream) {
-    if (!m) return fail(MDK_ERR_ARG, "null model");
-    if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
+// all passes of one call; x_host / probs_host (may be null) select the streamed host path per pass
+static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
+                      const float *x_host, float *probs_host) {
     memset(&m->last, 0, sizeof(m->last));
     m->last.n_layers = m->desc.num_layers;
-    if (B == 0 || T == 0) return MDK_OK;
-    if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
-    HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = (hipStream_t)stream;   // NULL = the legacy default stream, as for any HIP call
     // windows per pass, bounded so that the workspace stays within a fixed column budget
     // and balanced: equal passes keep every launch's grid full (a 838 + 162 split of 1000 windows
     // costs two full-length recurrences; 2 x 500 costs the same two, 1 x 1000 costs one)
@@ -662,22 +776,31 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     int rc = ensure_workspace(m, ((per_pass + kTileWin - 1) / kTileWin * kTileWin) * (size_t)T);
     if (rc) return rc;
     EvTimer tm{m, s};
+    const size_t F = m->desc.num_features, C = m->desc.num_classes;
     for (size_t b0 = 0; b0 < (size_t)B; b0 += per_pass) {
         const int nb = (int)std::min(per_pass, (size_t)B - b0);
-        rc = forward_pass(m, x_dev + b0 * T * m->desc.num_features, nb, T,
-                          probs_dev + b0 * T * m->desc.num_classes, s, tm);
+        HostIO io;
+        if (x_host) io.x_host = x_host + b0 * T * F;
+        if (probs_host) io.p_host = probs_host + b0 * T * C;
+        rc = forward_pass(m, x_dev + b0 * T * F, nb, T, probs_dev + b0 * T * C, s, tm,
+                          (x_host || probs_host) ? &io : nullptr);
         if (rc) return rc;
     }
     return finish_timing(m, tm, s);
 }
 
-extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host) {
+extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
+                                   void *stream) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
-    if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); return MDK_OK; }
-    if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); m->last.n_layers = m->desc.num_layers; return MDK_OK; }
+    if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
-    const size_t nx = (size_t)B * T * m->desc.num_features, np = (size_t)B * T * m->desc.num_classes;
+    // NULL = the legacy default stream, as for any HIP call
+    return run_passes(m, x_dev, B, T, probs_dev, (hipStream_t)stream, nullptr, nullptr);
+}
+
+static int ensure_staging(mdk_gru *m, size_t nx, size_t np) {
     if (nx > m->x_cap) {
         free_dev(m->x_dev); m->x_dev = nullptr; m->x_cap = 0;
         HIP_TRY(hipMalloc((void **)&m->x_dev, nx * sizeof(float)));
@@ -688,25 +811,22 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
         HIP_TRY(hipMalloc((void **)&m->p_dev, np * sizeof(float)));
         m->p_cap = np;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (m->timing) {
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventCreate(&e2)); HIP_TRY(hipEventCreate(&e3));
-        HIP_TRY(hipEventRecord(e0, m->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(m->x_dev, x_host, nx * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    if (m->timing) HIP_TRY(hipEventRecord(e1, m->stream));
-    int rc = mdk_gru_forward_dev(m, m->x_dev, B, T, m->p_dev, m->stream);
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (B < 0 || T < 0) return fail(MDK_ERR_ARG, "negative shape B=%d T=%d", B, T);
+    if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); return MDK_OK; }
+    if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t nx = (size_t)B * T * m->desc.num_features, np = (size_t)B * T * m->desc.num_classes;
+    int rc = ensure_staging(m, nx, np);
     if (rc) return rc;
-    if (m->timing) HIP_TRY(hipEventRecord(e2, m->stream));
-    HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    if (m->timing) HIP_TRY(hipEventRecord(e3, m->stream));
+    // x streams in and the probabilities stream out while the recurrences run (forward_pass, HostIO)
+    rc = run_passes(m, m->x_dev, B, T, m->p_dev, m->stream, x_host, probs_host);
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }   // nothing of ours may still touch the caller's buffers
     HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->timing) {
-        HIP_TRY(hipEventElapsedTime(&m->last.h2d_ms, e0, e1));
-        HIP_TRY(hipEventElapsedTime(&m->last.d2h_ms, e2, e3));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
-    }
     return MDK_OK;
 }
 
@@ -749,16 +869,7 @@ static int forward_any(mdk_gru *m, const float *x_host, const uint16_t *counts_h
     HIP_TRY(hipSetDevice(m->device));
     const int F = m->desc.num_features, C = m->desc.num_classes;
     const size_t cols = (size_t)B * T, nx = cols * F, np = cols * C;
-    if (nx > m->x_cap) {
-        free_dev(m->x_dev); m->x_dev = nullptr; m->x_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m->x_dev, nx * sizeof(float)));
-        m->x_cap = nx;
-    }
-    if (np > m->p_cap) {
-        free_dev(m->p_dev); m->p_dev = nullptr; m->p_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m->p_dev, np * sizeof(float)));
-        m->p_cap = np;
-    }
+    { int rc0 = ensure_staging(m, nx, np); if (rc0) return rc0; }
     // aux: [depth u32 | pmax f32 (cols)] [counts u16 (cols*F)] [cls u8 (cols)], 16-byte aligned pieces
     const size_t off_counts = (cols * 4 + 15) / 16 * 16, off_cls = off_counts + (cols * F * 2 + 15) / 16 * 16;
     const size_t aux_need = off_cls + cols;
@@ -775,12 +886,10 @@ static int forward_any(mdk_gru *m, const float *x_host, const uint16_t *counts_h
         HIP_TRY(hipMemcpyAsync(cd, counts_host, cols * F * 2, hipMemcpyHostToDevice, s));
         int rc = mdk_normalise_counts_dev(cd, dd, (long)cols, F, m->x_dev, m->device, s);
         if (rc) return rc;
-    } else {
-        HIP_TRY(hipMemcpyAsync(m->x_dev, x_host, nx * sizeof(float), hipMemcpyHostToDevice, s));
     }
-    int rc = mdk_gru_forward_dev(m, m->x_dev, B, T, m->p_dev, s);
-    if (rc) return rc;
-    if (probs_host) HIP_TRY(hipMemcpyAsync(probs_host, m->p_dev, np * sizeof(float), hipMemcpyDeviceToHost, s));
+    // float features stream in, probabilities (if wanted) stream out under the recurrences (HostIO)
+    int rc = run_passes(m, m->x_dev, B, T, m->p_dev, s, counts_host ? nullptr : x_host, probs_host);
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
     if (cls_host) {
         float *pm = reinterpret_cast<float *>(m->aux_dev);          // depth is dead by now
         uint8_t *cl = m->aux_dev + off_cls;
@@ -863,6 +972,18 @@ extern "C" int mdk_dev_alloc(int device, size_t bytes, void **ptr) {
 extern "C" int mdk_dev_free(int device, void *ptr) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(ptr));
+    return MDK_OK;
+}
+// page-locked host memory: buffers handed to mdk_gru_forward / mdk_rl_forward from here are copied by
+// DMA without a staging pass and are never page-faulted in by the copy (a fresh 40 MB malloc costs 3.6 ms
+// of first-touch faults as a copy target: profiles/r2_host_path_probe.txt)
+extern "C" int mdk_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(MDK_ERR_ARG, "null argument");
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return MDK_OK;
+}
+extern "C" int mdk_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return MDK_OK;
 }
 extern "C" int mdk_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {

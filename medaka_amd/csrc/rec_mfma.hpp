@@ -22,6 +22,14 @@
 
 namespace mdk {
 
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+constexpr int kSplSpinLimit = 1 << 18;       // polls (~100 cycles each) before a wave stops waiting: never a hang
+
+// byte offset of a __shared__ object inside the work-group's LDS allocation
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
+}
+
 constexpr int kHGroupStride = 272;          // bytes: 16 rows x 16 B + 16 B pad (bank spread)
 constexpr int kHKStride = 4 * kHGroupStride;  // one k-step (32 units) of the A image
 constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
@@ -47,7 +55,18 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // row per window (row 4g + q, up to NQ = 4 -> 16 windows per work-group), 12 MFMAs per wave.
 // CELL: 0 = GRU (3 gate tiles r,z,n), 1 = LSTM (4 gate tiles i,f,g,o; PyTorch nn.LSTM cell, used by
 // the read-level model, reference latent_space_lstm.py:129-149).
-template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0>
+// SPL: split synchronisation instead of one s_barrier per step.  The two waves of a SIMD share its
+// matrix pipe, so the second-dispatched half of the work-group (waves 4..7) runs its 24 MFMAs ~300-400
+// cycles behind the first half (waves 0..3) and, under a barrier, everybody waits for it and then
+// everybody waits again for LDS.  With SPL each wave publishes "my 16 units of step i are in LDS" in a
+// per-wave flag word, and a step consumes the h image in two halves: k-steps 0,1 (units of waves 0..3)
+// as soon as those four flags are up, k-steps 2,3 (waves 4..7) as soon as theirs are.  The early half's
+// next-step MFMAs then run under the late half's gate math and vice versa: the matrix pipe stays busy
+// across the step boundary.  Safety of the double-buffered image: a wave writes h(i+1) into the buffer
+// h(i-1) was read from only after its own step-(i+1) MFMAs, which needed every wave's flag for step i,
+// which each wave raises after its last read of h(i-1).  LDS executes one wave's operations in order,
+// so "h stores, then flag store" needs no wait in between; compiler barriers keep the program order.
+template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, bool SPL = false>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -61,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                       // s0 > 0 resumes from the h this kernel stored at scan step s0 - 1 (GRU only)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
+    __shared__ __attribute__((aligned(16))) unsigned int hflag[8];   // SPL: steps completed by wave w8 (0..3 | 4..7)
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
     if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
 
@@ -100,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             for (int sp = 0; sp < NS; ++sp) wx[gate][sp] = wp[(size_t)(gate * 2 + sp) * 64];
     }
     for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+    if (tid < 8) hflag[tid] = 0u;
 
     const int u = 16 * w8 + c;
     const float bhn = CELL ? 0.f : b_hn[d * kH + u] * (1.0f / inv_scale);
@@ -235,6 +256,199 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     };
     if constexpr (ABL & 64) tprev = __builtin_amdgcn_s_memtime();
 
+    // ---- SPL: one step with split synchronisation (see the template comment) ------------------------
+    static_assert(!(SPL && ABL), "ablation builds use the barrier schedule");
+    const unsigned flag_off = lds_offset(hflag);
+    bool spl_dead = false;       // a wait timed out: stop waiting (results are then wrong, the tests fail loudly)
+    // wait until the four waves of `half` (0: waves 0..3, 1: waves 4..7) have published `target` steps
+    auto wait_half = [&](int half, unsigned target) {
+        if (spl_dead) return;
+        int spins = 0;
+        while (true) {
+            uintx4 f;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag_off + 16u * half) : "memory");
+            const unsigned lo = min(min(f[0], f[1]), min(f[2], f[3]));
+            if ((int)(__builtin_amdgcn_readfirstlane(lo) - target) >= 0) break;
+            if (++spins > kSplSpinLimit) { spl_dead = true; break; }
+        }
+    };
+    auto spl_step = [&](int step, int p, int cur, int nxt) {
+        const unsigned done = (unsigned)(step - s0);     // steps every wave has to have published before this one
+        auto rows = [&](const floatx4 &v, int q) {
+            if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
+        };
+        auto rd = [&](int ks) { return *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off); };
+        float hn[NQ];
+        if constexpr (CELL == 0) {
+            floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
+            if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
+            // ---- first half of K: units of waves 0..3
+            wait_half(0, done);
+            const half8 a0 = rd(0), a1 = rd(1);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ar = mfma16(a0, wf[0][0][sp], ar);
+                az = mfma16(a0, wf[0][1][sp], az);
+            }
+            anh = mfma16(a0, wf[0][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a0, wf[0][2][1], anl);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ar = mfma16(a1, wf[1][0][sp], ar);
+                az = mfma16(a1, wf[1][1][sp], az);
+            }
+            anh = mfma16(a1, wf[1][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a1, wf[1][2][1], anl);
+            // refill the ring slot consumed in the PREVIOUS step; unconditional, in ring order
+            refill((p + PF - 1) % PF, (step + PF) < s_end);
+            // ---- second half of K: units of waves 4..7 (their gate math ran under the MFMAs above)
+            wait_half(1, done);
+            const half8 a2 = rd(2), a3 = rd(3);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ar = mfma16(a2, wf[2][0][sp], ar);
+                az = mfma16(a2, wf[2][1][sp], az);
+            }
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ar = mfma16(a3, wf[3][0][sp], ar);
+                az = mfma16(a3, wf[3][1][sp], az);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            anh = mfma16(a2, wf[2][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a2, wf[2][2][1], anl);
+            anh = mfma16(a3, wf[3][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a3, wf[3][2][1], anl);
+            float rr[NQ], zz[NQ], gnv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float gr, gz;
+                if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = rows(gin, q); }
+                else { gr = gq[p][q * NG]; gz = gq[p][q * NG + 1]; gnv[q] = gq[p][q * NG + 2]; }
+                const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
+                const float tz = XIN ? rows(az, q) : (gz + rows(az, q));
+                rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float tn;
+                if constexpr (HP) tn = anh[q] + bhn;
+                else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
+                const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
+                hprev[q] = h;
+                hn[q] = h;
+            }
+        } else {
+            // ---- LSTM cell: all four gate tiles over the first half of K, then i, f, g over the second
+            // half and the o tile last with the cell update under its MFMAs
+            floatx4 ai = floatx4{0.f, 0.f, 0.f, 0.f}, af = ai, ag = ai, ao = ai;
+            wait_half(0, done);
+            const half8 a0 = rd(0), a1 = rd(1);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ai = mfma16(a0, wf[0][0][sp], ai);
+                af = mfma16(a0, wf[0][1][sp], af);
+                ag = mfma16(a0, wf[0][2][sp], ag);
+                ao = mfma16(a0, wf[0][3][sp], ao);
+            }
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ai = mfma16(a1, wf[1][0][sp], ai);
+                af = mfma16(a1, wf[1][1][sp], af);
+                ag = mfma16(a1, wf[1][2][sp], ag);
+                ao = mfma16(a1, wf[1][3][sp], ao);
+            }
+            refill((p + PF - 1) % PF, (step + PF) < s_end);
+            wait_half(1, done);
+            const half8 a2 = rd(2), a3 = rd(3);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ai = mfma16(a2, wf[2][0][sp], ai);
+                af = mfma16(a2, wf[2][1][sp], af);
+                ag = mfma16(a2, wf[2][2][sp], ag);
+            }
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                ai = mfma16(a3, wf[3][0][sp], ai);
+                af = mfma16(a3, wf[3][1][sp], af);
+                ag = mfma16(a3, wf[3][2][sp], ag);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) ao = mfma16(a2, wf[2][3][sp], ao);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) ao = mfma16(a3, wf[3][3][sp], ao);
+            float tc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float ti = gq[p][q * NG + 0] + rows(ai, q);
+                const float tf = gq[p][q * NG + 1] + rows(af, q);
+                const float tg = gq[p][q * NG + 2] + rows(ag, q);
+                const float iv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ti * c_sig));
+                const float fv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tf * c_sig));
+                const float gv = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tg * c_tanh)), 1.0f);
+                const float cv = __builtin_fmaf(fv, hprev[q], iv * gv);
+                hprev[q] = cv;
+                tc[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * 2.88539008177792681472f)), 1.0f);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float to = gq[p][q * NG + 3] + rows(ao, q);
+                const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(to * c_sig));
+                hn[q] = ov * tc[q];
+            }
+        }
+        // ---- publish h: the fp16 image for the next step first (that is what the other waves wait for),
+        // then the flag, then the HBM store of the layer output
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            _Float16 hi, lo;
+            split_f16(hn[q] * kActScale, hi, lo);
+            if constexpr (HP) {
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
+            } else {
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+            }
+        }
+        asm volatile("ds_write_b32 %0, %1" ::"v"(flag_off + 4u * (unsigned)w8), "v"(done + 1u) : "memory");
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (step < s_end) op[q][0] = hn[q];
+            op[q] += ostride;
+        }
+        if constexpr (XIN) {
+            // layer-0 input projection of the NEXT step: independent of h, issued here so that it runs on
+            // the matrix pipe while this wave waits for the other waves' flags
+            const half8 xn = xq[(p + 1) % PF];
+            const floatx4 zero = floatx4{0.f, 0.f, 0.f, 0.f};
+            xar = mfma16(xn, wx[0][0], zero);
+            xaz = mfma16(xn, wx[1][0], zero);
+            xgn = mfma16(xn, wx[2][0], zero);
+            if constexpr (!HP) {
+                xar = mfma16(xn, wx[0][1], xar);
+                xaz = mfma16(xn, wx[1][1], xaz);
+                xgn = mfma16(xn, wx[2][1], xgn);
+            }
+        }
+    };
+
     for (int step0 = s0; step0 < s_end; step0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -245,6 +459,10 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 stamp(0);   // refill issue + loop overhead
 
                 half8 a[4];
+                if constexpr (SPL) {
+                    spl_step(step, p, cur, nxt);
+                    continue;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
@@ -435,15 +653,16 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 static __global__ __launch_bounds__(256) void k_pack_x(
     const float *__restrict__ x,   // [B][T][I]
     half8 *__restrict__ xfrag,     // [n_wg][T][64]
-    int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor)
+    int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor,
+    int t_lo, int nt)              // columns [t_lo, t_lo + nt) of every window (the host path streams x in time slabs)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)n_wg * T * 64;
+    const size_t total = (size_t)n_wg * nt * 64;
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     const size_t wt = idx >> 6;
-    const int t = (int)(wt % T);
-    const int wg = (int)(wt / T);
+    const int t = t_lo + (int)(wt % nt);
+    const int wg = (int)(wt / nt);
     const int row = lane & 15, gq = lane >> 4;
     // row -> (window slot q of lane-group g, hi|lo piece): fp32-parity 4g + 2q + split, half 4g + q
     const int g = row >> 2;
@@ -466,7 +685,7 @@ static __global__ __launch_bounds__(256) void k_pack_x(
         split_f16(val, hi, lo);
         v[i] = split ? lo : hi;
     }
-    xfrag[idx] = v;
+    xfrag[((size_t)wg * T + t) * 64 + lane] = v;
     if (bad) atomicOr(oor, 1);
 }
 

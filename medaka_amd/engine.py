@@ -1,6 +1,6 @@
-"""Thin object wrapper over the C ABI (include/medaka_amd.h): one `GruEngine` = one `mdk_gru*`.
+"""Object wrapper over the C ABI (include/medaka_amd.h): one `GruEngine` = one `mdk_gru*`.
 
-This is the layer `models.HipGRUModel` (the drop-in for reference
+This is the layer `models.GRUModel` (the drop-in for reference
 `medaka.architectures.GRUModel`) sits on; tests and bench.py also drive it directly.
 """
 import ctypes
@@ -47,6 +47,30 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             _lib.load().mdk_dev_free(self.device, self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """Page-locked host buffer from the C ABI (`mdk_host_alloc`) with a numpy view: reusable input /
+    output of `GruEngine.forward_host(x, out=...)` for hosts without torch's pinned allocator."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.ptr = ctypes.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _lib.check(_lib.load().mdk_host_alloc(max(nbytes, 1), ctypes.byref(self.ptr)), "mdk_host_alloc")
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            _lib.load().mdk_host_free(self.ptr)
             self.ptr = ctypes.c_void_p()
 
     def __del__(self):
@@ -120,6 +144,8 @@ class GruEngine:
         B, T, _ = x.shape
         if out is None:
             out = np.empty((B, T, self.num_classes), dtype=np.float32)
+        elif out.shape != (B, T, self.num_classes) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 (B, T, num_classes) array")
         _lib.check(_lib.load().mdk_gru_forward(self._h, x.ctypes.data, B, T, out.ctypes.data),
                    "mdk_gru_forward")
         return out

@@ -1,0 +1,196 @@
+"""N-GPU launcher for the consensus inference step (BASELINE configs 3 and 5).
+
+    python -m medaka_amd.launch --gpus 8 calls_to_draft.bam draft.fasta outdir \
+        --model r1041_e82_400bps_sup_v5.0.0 --batch_size 200 [-- <extra medaka inference args>]
+
+The reference's own recipe for scaling is one `medaka inference --regions ...` job per batch of regions,
+then one `medaka sequence *.hdf` (reference README.md:294-330; `medaka_consensus` itself runs a single
+job, scripts/medaka_consensus:185-199).  This launcher is that recipe for one node of MI355X:
+
+  1. contig lengths from `draft.fasta.fai` (or a scan of the FASTA);
+  2. `sharding.shard_regions`: the regions `medaka inference` would cut for itself (prediction.py:100-110),
+     dealt longest-first to N shards -- so the union of the shards' samples is exactly a single run's;
+  3. one child per GPU with `HIP_VISIBLE_DEVICES=i` (the reference takes device 0 of the visible set,
+     prediction.py:136-138) and `MEDAKA_AMD=1` (swaps the engine in at `ModelStoreTGZ.load_model`,
+     medaka_amd/integration.py): `medaka inference <bam> <outdir>/shard_i.hdf --regions shard_i.bed ...`;
+  4. waits; if one child fails the others are stopped and the launcher exits non-zero;
+  5. prints -- with `--sequence` also runs -- `medaka sequence shard_*.hdf draft.fasta consensus.fasta`.
+
+No collective anywhere: windows never exchange state.  The children are ordinary processes, not
+torch.distributed ranks; nothing is shared but the page cache of the BAM.
+"""
+import argparse
+import os
+import shlex
+import signal
+import subprocess
+import sys
+import time
+
+from medaka_amd import sharding
+
+
+def contig_lengths(draft):
+    """[(name, length)] in file order, from the .fai index when present."""
+    fai = draft + ".fai"
+    if os.path.exists(fai):
+        out = []
+        for line in open(fai):
+            f = line.rstrip("\n").split("\t")
+            if len(f) >= 2:
+                out.append((f[0], int(f[1])))
+        return out
+    out, name, n = [], None, 0
+    with open(draft) as fh:
+        for line in fh:
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, n))
+                name, n = line[1:].split()[0], 0
+            else:
+                n += len(line.strip())
+    if name is not None:
+        out.append((name, n))
+    return out
+
+
+def plan(draft, n_gpus, bam_chunk, chunk_ovlp, regions=None):
+    """Per-GPU region lists.  `regions`: optional subset as 'name' or 'name:start-end' strings."""
+    contigs = contig_lengths(draft)
+    if regions:
+        lengths = dict(contigs)
+        picked = []
+        for r in regions:
+            name, start, end = r, 0, None
+            if ":" in r:
+                head, tail = r.rsplit(":", 1)
+                a, _, b = tail.partition("-")
+                if a.isdigit() and b.isdigit():
+                    name, start, end = head, int(a), int(b)
+            if name not in lengths:
+                raise KeyError(f"{name} is not a sequence of {draft}")
+            picked.append(sharding.Region(name, start, min(end, lengths[name]) if end is not None else lengths[name]))
+        contigs = picked
+    return sharding.shard_regions(contigs, n_gpus, bam_chunk=bam_chunk, chunk_ovlp=chunk_ovlp)
+
+
+def write_bed(path, regions):
+    with open(path, "w") as fh:
+        for r in regions:
+            fh.write(f"{r.ref_name}\t{r.start}\t{r.end}\n")
+
+
+def build_commands(args, shards):
+    """[(env additions, argv, hdf path)] for the non-empty shards."""
+    jobs = []
+    base = shlex.split(args.inference_cmd)
+    for i, regs in enumerate(shards):
+        if not regs:
+            continue
+        bed = os.path.join(args.outdir, f"shard_{i}.bed")
+        hdf = os.path.join(args.outdir, f"shard_{i}.hdf")
+        write_bed(bed, regs)
+        argv = base + [args.bam, hdf, "--regions", bed, "--batch_size", str(args.batch_size),
+                       "--chunk_len", str(args.chunk_len), "--chunk_ovlp", str(args.chunk_ovlp),
+                       "--bam_chunk", str(args.bam_chunk), "--threads", str(args.threads),
+                       "--bam_workers", str(args.bam_workers)]
+        if args.model:
+            argv += ["--model", args.model]
+        argv += args.extra
+        env = {"HIP_VISIBLE_DEVICES": str(args.first_gpu + i), "MEDAKA_AMD": "0" if args.reference_model else "1",
+               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        jobs.append((env, argv, hdf))
+    return jobs
+
+
+def run(jobs, poll_s=0.5, log_dir=None):
+    """Start every job, wait; on the first failure stop the rest.  Returns the list of return codes."""
+    procs = []
+    for k, (env, argv, _) in enumerate(jobs):
+        full_env = dict(os.environ, **env)
+        full_env.pop("CUDA_VISIBLE_DEVICES", None)       # one selector only: HIP_VISIBLE_DEVICES
+        log = open(os.path.join(log_dir, f"shard_{env['HIP_VISIBLE_DEVICES']}.log"), "w") if log_dir else None
+        procs.append((subprocess.Popen(argv, env=full_env, stdout=log, stderr=subprocess.STDOUT if log else None,
+                                       start_new_session=True), log))
+    codes = [None] * len(procs)
+    try:
+        while any(c is None for c in codes):
+            for k, (p, _) in enumerate(procs):
+                if codes[k] is None:
+                    codes[k] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                break
+            time.sleep(poll_s)
+    finally:
+        for k, (p, log) in enumerate(procs):
+            if p.poll() is None:                          # stop exactly the process groups we started
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)
+                    p.wait()
+            codes[k] = p.returncode
+            if log:
+                log.close()
+    return codes
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m medaka_amd.launch", description=__doc__.split("\n\n")[0])
+    ap.add_argument("bam")
+    ap.add_argument("draft", help="draft assembly FASTA (its .fai is used when present)")
+    ap.add_argument("outdir")
+    ap.add_argument("--gpus", type=int, default=8)
+    ap.add_argument("--first-gpu", type=int, default=0, dest="first_gpu")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--regions", nargs="+", default=None, help="restrict to these contigs / regions")
+    ap.add_argument("--batch_size", type=int, default=200)
+    ap.add_argument("--chunk_len", type=int, default=10000)      # reference defaults: medaka.py:266-272
+    ap.add_argument("--chunk_ovlp", type=int, default=1000)
+    ap.add_argument("--bam_chunk", type=int, default=1_000_000)
+    ap.add_argument("--threads", type=int, default=2)            # README.md:332-336
+    ap.add_argument("--bam_workers", type=int, default=2)
+    ap.add_argument("--inference-cmd", default="medaka inference", dest="inference_cmd",
+                    help="command that runs one shard (tests substitute a stub)")
+    ap.add_argument("--sequence-cmd", default="medaka sequence", dest="sequence_cmd")
+    ap.add_argument("--sequence", action="store_true", help="also run `medaka sequence` over the shard HDFs")
+    ap.add_argument("--reference-model", action="store_true", dest="reference_model",
+                    help="children keep the reference's own PyTorch model (MEDAKA_AMD=0)")
+    ap.add_argument("--dry-run", action="store_true", dest="dry_run", help="write the BED files, print the commands")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    extra = []
+    if "--" in argv:                      # everything after `--` is passed through to every child
+        cut = argv.index("--")
+        argv, extra = argv[:cut], argv[cut + 1:]
+    args = ap.parse_args(argv)
+    args.extra = extra
+    return args
+
+
+def main(argv=None):
+    args = parse(argv)
+    os.makedirs(args.outdir, exist_ok=True)
+    shards = plan(args.draft, args.gpus, args.bam_chunk, args.chunk_ovlp, args.regions)
+    jobs = build_commands(args, shards)
+    for env, cmd, _ in jobs:
+        print("HIP_VISIBLE_DEVICES=%s MEDAKA_AMD=%s %s" % (env["HIP_VISIBLE_DEVICES"], env["MEDAKA_AMD"], shlex.join(cmd)))
+    seq = shlex.split(args.sequence_cmd) + [h for _, _, h in jobs] + [args.draft, os.path.join(args.outdir, "consensus.fasta")]
+    print(shlex.join(seq))
+    if args.dry_run:
+        return 0
+    t0 = time.time()
+    codes = run(jobs, log_dir=args.outdir)
+    print(f"{len(jobs)} inference jobs finished in {time.time() - t0:.1f}s, return codes {codes}", file=sys.stderr)
+    if any(c != 0 for c in codes):
+        return 1
+    if args.sequence:
+        return subprocess.call(seq)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -68,6 +68,8 @@ ABI = {
     "mdk_device_name": (_i, [_i, ctypes.c_char_p, _sz]),
     "mdk_dev_alloc": (_i, [_i, _sz, ctypes.POINTER(_vp)]),
     "mdk_dev_free": (_i, [_i, _vp]),
+    "mdk_host_alloc": (_i, [_sz, ctypes.POINTER(_vp)]),
+    "mdk_host_free": (_i, [_vp]),
     "mdk_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
     "mdk_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
     "mdk_device_synchronize": (_i, [_i]),

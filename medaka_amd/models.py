@@ -26,6 +26,18 @@ from medaka_amd import engine as _engine
 from medaka_amd import lib as _lib
 
 
+def _host_output(shape):
+    """CPU float32 tensor for `predict_on_batch` to return (models.py:312 `.cpu()`), page-locked: torch's
+    caching host allocator recycles the block once every view the caller keeps (the HDF writer holds the
+    per-sample rows, datastore.py:283-300) is gone, so steady-state batches neither allocate nor
+    page-fault -- a fresh 40 MB pageable tensor costs 3.6 ms of first-touch faults as a DMA target
+    (profiles/r2_host_path_probe.txt)."""
+    try:
+        return torch.empty(shape, dtype=torch.float32, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(shape, dtype=torch.float32)
+
+
 class TorchModel(torch.nn.Module):
     """Base class mirroring reference `medaka.models.TorchModel` (models.py:277-365)."""
 
@@ -179,7 +191,7 @@ class GRUModel(CountsMatrixModel):
             if x.dim() != 3 or x.shape[2] != self.num_features:
                 raise ValueError(f"expected (B, T, {self.num_features}) input, got {tuple(x.shape)}")
             B, T, _ = x.shape
-            out = torch.empty((B, T, 5), dtype=torch.float32)
+            out = _host_output((B, T, 5))
             eng.forward_ptr(x.data_ptr(), B, T, out.data_ptr(), host=True)
             return out
         return self.forward(x).detach().cpu()
