@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
+    ap.add_argument("--split-sync", type=int, default=0, help="recurrence: per-wave flags + half-K waits (1) or one barrier per step (0)")
+    ap.add_argument("--z-last", type=int, default=None, help="recurrence: z tile last (engine default if omitted)")
+    ap.add_argument("--model", default="gru", choices=["gru", "rl128", "rl384"],
+                    help="gru: the headline consensus model; rl128 / rl384: read-level models (BASELINE config 4b)")
+    ap.add_argument("--rl-depth", type=int, default=50, help="read-level models: reads per window")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
     return ap.parse_args()
 
@@ -140,8 +145,108 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
     return base, parity
 
 
+RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
+
+
+def main_rl(args):
+    """BASELINE config 4b: the read-level model (reference LatentSpaceLSTM) over uint8 read matrices, one GPU
+    per rank, input resident in HBM.  rl384 = the bundled rl_lstm384 architecture (lstm 384, 4 x uni-directional,
+    dwells), weights from a seed (20 MB, not committed); rl128 = class defaults, committed trained-like weights."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as graft
+    graft.build()
+    from medaka_amd import dist, models, synth
+    ranks = dist.Ranks()
+    if ranks.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback of the engine")
+    dev = torch.device("cuda", ranks.local_rank)
+    torch.cuda.set_device(dev)
+    wide = args.model == "rl384"
+    B = args.batch if args.batch != 200 else 100            # reference CLI default batch for these models
+    P, D = args.chunk_len, args.rl_depth
+    if wide:
+        kw = dict(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False)
+        state = synth.synth_rl_state(seed=21, **kw)
+    else:
+        kw = dict()
+        state = dict(np.load(os.path.join(ROOT, "tests", "golden", "rl_weights_trained.npz")))
+    m = models.LatentSpaceLSTM(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+    m = m.to(dev).eval()
+    if args.half:
+        m.half()
+    x_small = synth.synth_reads(min(B, 8), P, D, use_dwells=wide, seed=1 + ranks.rank, empty_tail=False)
+    x = torch.from_numpy(x_small).repeat((B + x_small.shape[0] - 1) // x_small.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    eng = m.engine()
+    eng.enable_timing(True)
+    front, total = [], []
+    holder = {}
+
+    def step():
+        with torch.inference_mode():
+            holder["y"] = m(x)
+        t = eng.timing()
+        front.append(t["front_ms"]); total.append(t["total_ms"])
+    elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=args.steps, warmup=args.warmup)
+    front, total = front[-args.steps:], total[-args.steps:]
+    cols = B * P
+    value = ranks.world * cols * args.steps / elapsed
+    issue = 1 if args.half else 3           # fp32 parity: hi*hi + lo*hi + hi*lo products on the fp16 pipe
+    flop = RL_CONV2_FLOP * float(B) * P * D
+    achieved = flop / (statistics.mean(front) * 1e-3) / 1e12
+    result = {
+        "metric": "pileup columns/sec (read-level CNN + LSTM inference)", "value": value, "unit": "pileup columns/s",
+        "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
+                 "f32 (fp16 hi+lo split operands on the fp16 matrix pipe, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": f"LatentSpaceLSTM({'lstm 384, 4 x uni-directional, dwells: rl_lstm384 architecture' if wide else 'lstm 128, bi-directional'}), "
+                               f"batch {B} windows x {P} positions x {D} reads (uint8 read matrix), input resident in HBM",
+                   "batch_windows": B, "chunk_len": P, "reads_per_window": D,
+                   "read_positions_per_s": value * D,
+                   "weights": "synth.synth_rl_state(seed=21)" if wide else "tests/golden/rl_weights_trained.npz",
+                   "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"},
+        "roofline": {"kernel": "k_rl_front (embedding + conv1 + BN + conv17 as an implicit GEMM on MFMA + BN + masked mean over reads)",
+                     "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_DENSE_TFLOPS / issue, "unit": "TFLOP/s",
+                     "frac": achieved / (PEAK_F16_DENSE_TFLOPS / issue), "traffic": None,
+                     "avg_launch_ms": statistics.mean(front), "launches_timed": len(front),
+                     "algorithmic_flop_per_launch": flop,
+                     "note": f"algorithmic = conv2 only, {RL_CONV2_FLOP} FLOP per (window, read, position); peak = fp16 dense "
+                             f"{PEAK_F16_DENSE_TFLOPS:.0f} TFLOP/s / {issue} fp16 products issued per algorithmic MAC",
+                     "kernel_ms_per_step": {"front": statistics.mean(front), "device_total": statistics.mean(total)},
+                     "wide_retries": eng.timing()["wide_retries"]},
+    }
+    if ranks.rank == 0:
+        if args.cpu_budget > 0 and ranks.world == 1:
+            # CPU baseline: the functional PyTorch-CPU restatement of LatentSpaceLSTM.forward on a bounded sample
+            from oracle import rl_oracle
+            xs = x_small[:2, :min(P, 400)]
+            torch.set_num_threads(min(usable_cores(), 16))
+            rl_oracle.rl_forward(xs[:1, :50], state, use_dwells=wide, bidirectional=not wide)
+            t0 = time.perf_counter()
+            ref = rl_oracle.rl_forward(xs, state, use_dwells=wide, bidirectional=not wide)
+            dt = time.perf_counter() - t0
+            with torch.inference_mode():
+                out = m(torch.from_numpy(np.ascontiguousarray(xs)).to(dev)).cpu().numpy()
+            result["cpu_baseline"] = {"value": xs.shape[0] * xs.shape[1] / dt, "unit": "pileup columns/s",
+                                      "cores": min(usable_cores(), 16), "kind": "port",
+                                      "sample": f"{xs.shape[0]} windows x {xs.shape[1]} positions x {D} reads, "
+                                                "oracle/rl_oracle.py (functional PyTorch-CPU fp32), one pass"}
+            result["parity"] = {"max_abs_dp": float(np.abs(out - ref).max()),
+                                "argmax_identical": bool((out.argmax(-1) == ref.argmax(-1)).all()),
+                                "columns_checked": int(xs.shape[0] * xs.shape[1])}
+        print(json.dumps(result), flush=True)
+    ranks.close()
+
+
 def main():
     args = parse()
+    if args.model != "gru":
+        return main_rl(args)
     import numpy as np
     import torch
     import __graft_entry__ as graft
@@ -178,6 +283,9 @@ def main():
     eng = model.engine()
     eng.set_option("rec_windows_per_tile", args.tile)
     eng.set_option("overlap_gemm", args.overlap)
+    eng.set_option("split_sync", args.split_sync)
+    if args.z_last is not None:
+        eng.set_option("z_last", args.z_last)
     eng.enable_timing(True)
 
     out_holder = {}
@@ -216,6 +324,7 @@ def main():
         t0 = time.perf_counter()
         out_holder["p"] = model.predict_on_batch(xb)
         h2h.append(time.perf_counter() - t0)
+    log('host-to-host batches')
     h_elapsed, _ = dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
     h2h = h2h[2:]
     h_med = ranks.max_over_ranks(statistics.median(h2h))
@@ -226,6 +335,7 @@ def main():
         model.predict_on_batch(xb)
         plain.append(time.perf_counter() - t0)
     eng.set_option("stream_host", 1)
+    log(f'host-to-host done: median {1e3 * h_med:.2f} ms streamed, {1e3 * statistics.median(plain):.2f} ms unstreamed')
 
     result = {
         "metric": "pileup columns/sec (consensus bi-GRU inference)",

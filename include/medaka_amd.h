@@ -147,11 +147,12 @@ int mdk_majority_forward(const float *x_host, long n_cols, float *probs_host, in
  * Read-level model (reference `LatentSpaceLSTM`, medaka/architectures/latent_space_lstm.py:35-207):
  * Embedding + q-score (+ dwell) -> Conv1d(k=1) -> ReLU -> BN -> Conv1d(k=17) -> ReLU -> BN ->
  * Linear -> masked mean over reads -> 2-layer bi-LSTM or 4 alternating LSTMs -> Linear -> softmax.
- * Supported: lstm_size == cnn_size == 128, kernel_sizes [1, 17], embedding size 6, 5 classes.
+ * Supported: cnn_size == 128 with lstm_size == 128 (bi- or 4 x uni-directional) or lstm_size == 384
+ * uni-directional (the bundled rl_lstm384); kernel_sizes [1, 17], embedding size 6, alphabet <= 8, 5 classes.
  */
 typedef struct mdk_rl mdk_rl;
 typedef struct {
-    int lstm_size;       /* 128 */
+    int lstm_size;       /* 128 | 384 */
     int cnn_size;        /* 128 */
     int kernel_size0;    /* 1 */
     int kernel_size1;    /* 17 */
@@ -178,13 +179,29 @@ int mdk_rl_create(const mdk_rl_desc *desc, const float *const *weights, int n_we
 /* Replaces `TorchModel.predict_on_batch` for ReadLevelFeaturesModel input
  * (`batch.read_level_features`, base_classes.py:28-34): x uint8 (B, P, D, F) -> probs (B, P, 5). */
 int mdk_rl_forward(mdk_rl *m, const unsigned char *x_host, int B, int P, int D, int F, float *probs_host);
+/* Device-resident variant, enqueued on `stream`.  lstm_size 128: asynchronous.  lstm_size 384 (rl_lstm384): the
+ * cluster recurrence verifies its cross-CU exchange, so by default the call SYNCHRONISES `stream`, and after a
+ * time-out (a late cluster member: the path wants 192 CUs of the GPU to itself) re-runs once on the plain
+ * schedule before failing with MDK_ERR_DEVICE.  Option "wide_async" = 1 makes it asynchronous (no retry);
+ * mdk_rl_check() then reports a time-out of any earlier forward. */
 int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int D, int F, float *probs_dev,
                        void *stream);
+int mdk_rl_check(mdk_rl *m, void *stream);
+/* hipEvent timing of the following mdk_rl_forward_dev calls (adds a sync per forward): the fused read-level
+ * front end (k_rl_front: embedding + conv1 + BN + conv17 on MFMA + BN + masked mean), the dominant kernel. */
+typedef struct {
+    float front_ms;      /* k_rl_front */
+    float total_ms;      /* whole forward on the stream */
+    int wide_retries;    /* lstm_size 384: forwards re-run on the plain schedule after an exchange time-out */
+} mdk_rl_timing;
+int mdk_rl_enable_timing(mdk_rl *m, int on);
+int mdk_rl_get_timing(mdk_rl *m, mdk_rl_timing *out);
 int mdk_rl_set_precision(mdk_rl *m, int precision);
 int mdk_rl_set_normalise(mdk_rl *m, int normalise);
 /* Tuning / test knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8 | 16   lstm_size 128: recurrence work-group granularity
- *   "split_sync"           = 1 | 0                  lstm_size 128: recurrence with per-wave flags + half-K waits
+ *   "wide_async"           = 0 | 1                  lstm_size 384: do not synchronise in mdk_rl_forward_dev (see above)
+ *   "split_sync"           = 0 | 1                  lstm_size 128: recurrence with per-wave flags + half-K waits
  *   "overlap_gemm"         = 1 | 0                  lstm_size 384: next layer's projection on a side stream
  *                                                   behind resumable recurrence chunks (P >= 1024)
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through

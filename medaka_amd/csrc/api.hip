@@ -82,7 +82,8 @@ struct mdk_gru {
     float *gi2 = nullptr;                    // its own gi buffer (layer 0's fallback may still read gi)
     size_t gi2_rows = 0;
     int opt_overlap = 1;
-    int opt_split_sync = 1;                  // recurrence: per-wave flags and half-K waits instead of one barrier per step
+    int opt_split_sync = 0;                  // recurrence: 0 one barrier per step; 1 / 2 per-wave flags and half-K waits (rec_mfma.hpp SPL)
+    int opt_z_last = 0;                      // recurrence: z tile last (rec_mfma.hpp ZL)
     int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
     // timing
     bool timing = false;
@@ -306,7 +307,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
     } else if (!strcmp(key, "split_sync")) {
-        m->opt_split_sync = value ? 1 : 0;
+        m->opt_split_sync = value < 0 ? 0 : (value > 2 ? 2 : value);
+    } else if (!strcmp(key, "z_last")) {
+        m->opt_z_last = value ? 1 : 0;
     } else if (!strcmp(key, "stream_host")) {
         m->opt_stream_host = value ? 1 : 0;
 
@@ -544,10 +547,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     struct OutRange { hipEvent_t ready; int t0, nt; };
     std::vector<OutRange> out_ranges;   // head chunks to copy out; issued after every launch is enqueued, because a
                                         // copy into pageable memory may block the calling thread until it is done
-    auto pack_cols = [&](const LayerDev &Lp, const float *src, int t0, int nt) {
+    auto pack_cols = [&](const LayerDev &Lp, const float *src, int t0, int nt, hipStream_t st) {
         if (nt <= 0) return;
         const size_t need = (size_t)n_wg * nt * 64;
-        hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, src, m->xfrag, nb, T,
+        hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, src, m->xfrag, nb, T,
                            Lp.K, nq, hp ? 1 : 0, n_wg, Lp.x_scale, m->oor_flag, t0, nt);
     };
 
@@ -558,7 +561,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         const float *gi_src = (l == 1 && gemm_done) ? gi_l1 : m->gi;
         const bool fuse = (l == 0) && fuse0;
         const int *cond = fuse ? m->oor_flag : nullptr;
-        const bool slabs = stream_in && l == 0;                    // this layer's recurrence waits for x slab by slab
+        // device-resident x: the packing of all but the first slab pair runs on the side stream under the
+        // first recurrence phases instead of in front of them (0.25 ms of k_pack_x at 200 x 10000)
+        const bool dev_slabs = !io_in && fuse && can_chunk && l == 0 && m->opt_overlap;
+        const bool slabs = (stream_in || dev_slabs) && l == 0;       // this layer's recurrence starts slab by slab
         const bool side_gemm = overlap && l == 0;                  // layer 1's projection behind this layer's chunks
         const bool side_head = (overlap || stream_out) && l == L - 1 && L >= 2;   // classifier head behind the chunks
         if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
@@ -570,7 +576,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 m->xfrag_cap = need;
             }
             HIP_TRY(hipMemsetAsync(m->oor_flag, 0, sizeof(int), s));
-            if (!slabs) pack_cols(Ld, in, 0, T);
+            if (!slabs) pack_cols(Ld, in, 0, T, s);
         }
         // unfused layer-0 projection: the only path without fusion, the on-device fallback (input beyond
         // fp16 range) with it.  It reads all of x, so with slabs it is enqueued after the last of them.
@@ -587,13 +593,17 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         if ((rc = tm.end())) return rc;
         size_t rspan = 0;
         if ((rc = tm.begin(SLOT_REC0 + l, (hipStream_t)-1, &rspan))) return rc;
-#define MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, CND, WANT)                                        \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, A, SPLV>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+#define MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, ZLV, CND, WANT)                                   \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, A, SPLV, ZLV>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
                        Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
                        reverse_mask, CND, WANT, rs0, rns)
+#define MDK_LAUNCH_REC_Z(NQV, XIN, HPF, A, SPLV, CND, WANT)                                        \
+    do { if ((A) == 0 && m->opt_z_last) MDK_LAUNCH_REC_S(NQV, XIN, HPF, 0, SPLV, true, CND, WANT);  \
+         else MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, false, CND, WANT); } while (0)
 #define MDK_LAUNCH_REC(NQV, XIN, HPF, A, CND, WANT)                                                \
-    do { if ((A) == 0 && m->opt_split_sync) MDK_LAUNCH_REC_S(NQV, XIN, HPF, 0, true, CND, WANT);   \
-         else MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, false, CND, WANT); } while (0)
+    do { if ((A) == 0 && m->opt_split_sync == 1) MDK_LAUNCH_REC_Z(NQV, XIN, HPF, 0, 1, CND, WANT);   \
+         else if ((A) == 0 && m->opt_split_sync == 2) MDK_LAUNCH_REC_Z(NQV, XIN, HPF, 0, 2, CND, WANT); \
+         else MDK_LAUNCH_REC_Z(NQV, XIN, HPF, A, 0, CND, WANT); } while (0)
         // production instantiations
         auto launch = [&](bool xin, const int *cnd, int want) {
             if (hp) {
@@ -608,7 +618,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         // the fallback twin is instantiated with a different ring depth only so that profilers
         // show it under its own symbol (its launches are empty unless the range flag is raised)
 #define MDK_LAUNCH_FB(NQV, HPF)                                                                    \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF - 1, NQV, false, HPF, 0, 0, true>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF - 1, NQV, false, HPF, 0, 0, 0>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
                        Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
                        reverse_mask, cnd, 1, rs0, rns)
         auto launch_fallback = [&](const int *cnd) {
@@ -645,9 +655,28 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             const int n_ph = (int)ph.size() - 1;
             size_t gspan = 0;
             bool gspan_open = false;
+            hipEvent_t slab_ev[8] = {};
             for (int p = 0; p < n_ph; ++p) {
                 rs0 = ph[p]; rns = ph[p + 1] - ph[p];
-                if (slabs && p < n_first) {
+                if (slabs && p < n_first && dev_slabs) {
+                    if (p == 0) {
+                        pack_cols(Ld, in, 0, ph[1], s);
+                        pack_cols(Ld, in, T - ph[1], ph[1], s);
+                        hipEvent_t ev0;                        // x may come from earlier work on `s`
+                        if ((rc = pool_event(m, &ev0))) return rc;
+                        HIP_TRY(hipEventRecord(ev0, s));
+                        HIP_TRY(hipStreamWaitEvent(m->side, ev0, 0));
+                        for (int pp = 1; pp < n_first; ++pp) {
+                            const int lo = ph[pp], len = ph[pp + 1] - ph[pp];
+                            pack_cols(Ld, in, lo, len, m->side);
+                            pack_cols(Ld, in, T - lo - len, len, m->side);
+                            if ((rc = pool_event(m, &slab_ev[pp]))) return rc;
+                            HIP_TRY(hipEventRecord(slab_ev[pp], m->side));
+                        }
+                    } else {
+                        HIP_TRY(hipStreamWaitEvent(s, slab_ev[p], 0));
+                    }
+                } else if (slabs && p < n_first) {
                     // columns [rs0, rs0+rns) and their mirror [T-rs0-rns, T-rs0); the last pair is adjacent
                     const int lo = rs0, hi = T - rs0 - rns;
                     if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
@@ -656,7 +685,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                     if ((rc = pool_event(m, &ev))) return rc;
                     HIP_TRY(hipEventRecord(ev, m->copy_in));
                     HIP_TRY(hipStreamWaitEvent(s, ev, 0));
-                    if (fuse) { pack_cols(Ld, in, lo, rns); pack_cols(Ld, in, hi, rns); }
+                    if (fuse) { pack_cols(Ld, in, lo, rns, s); pack_cols(Ld, in, hi, rns, s); }
                 }
                 if (fuse) launch(true, cond, 0);   // (the unfused twin runs once, after the phases: see below)
                 else launch(false, nullptr, 0);
@@ -711,6 +740,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         }
 #undef MDK_LAUNCH_REC
 #undef MDK_LAUNCH_REC_S
+#undef MDK_LAUNCH_REC_Z
         if ((rc = tm.end_at(rspan))) return rc;
         m->last.rec_launches++;
         in = outp;

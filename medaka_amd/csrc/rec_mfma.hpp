@@ -66,7 +66,15 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // h(i-1) was read from only after its own step-(i+1) MFMAs, which needed every wave's flag for step i,
 // which each wave raises after its last read of h(i-1).  LDS executes one wave's operations in order,
 // so "h stores, then flag store" needs no wait in between; compiler barriers keep the program order.
-template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, bool SPL = false>
+// SPL = 2: the flag read and the two A-fragment reads of a half are issued together (LDS executes a wave's
+// operations in order and the producer stores the data before the flag, so a flag that reads "up" vouches
+// for the fragments read behind it); nothing is added to the critical path when the flag is already up,
+// and a miss sleeps 64 clocks before the retry instead of spinning on the issue port.
+// ZL (GRU): issue the r and n tiles first and the z tile LAST.  What follows the last MFMA is then only
+// sigmoid(z) and the blend h = n + z (h_prev - n) -- 7 dependent VALU operations instead of the 11 of the
+// tanh chain -- because sigmoid(r), tanh and (h_prev - n) run under the z tile's MFMAs.  Every accumulator
+// still receives its MFMAs in the same order, so the results are bit-identical to ZL = false.
+template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, int SPL = 0, bool ZL = false>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     if constexpr (ABL & 64) tprev = __builtin_amdgcn_s_memtime();
 
     // ---- SPL: one step with split synchronisation (see the template comment) ------------------------
-    static_assert(!(SPL && ABL), "ablation builds use the barrier schedule");
+    static_assert(!(SPL != 0 && ABL != 0), "ablation builds use the barrier schedule");
     const unsigned flag_off = lds_offset(hflag);
     bool spl_dead = false;       // a wait timed out: stop waiting (results are then wrong, the tests fail loudly)
     // wait until the four waves of `half` (0: waves 0..3, 1: waves 4..7) have published `target` steps
@@ -272,19 +280,101 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             if (++spins > kSplSpinLimit) { spl_dead = true; break; }
         }
     };
+    const unsigned img_off = lds_offset(hbuf) + (unsigned)rd_off;
+    // wait for `half` and read its two A fragments (k-steps 2*half, 2*half + 1 of the image at byte `cur`)
+    auto wait_read = [&](int half, unsigned target, int cur, half8 &x0, half8 &x1) {
+        if constexpr (SPL == 2) {
+            const unsigned a_off = img_off + (unsigned)cur + (unsigned)(2 * half) * kHKStride;
+            int spins = 0;
+            while (true) {
+                uintx4 f;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(f), "=&v"(x0), "=&v"(x1)
+                             : "v"(flag_off + 16u * half), "v"(a_off), "n"(kHKStride)
+                             : "memory");
+                const unsigned lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                if (spl_dead || (int)(__builtin_amdgcn_readfirstlane(lo) - target) >= 0) break;
+                if (++spins > kSplSpinLimit / 4) { spl_dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            wait_half(half, target);
+            x0 = *reinterpret_cast<const half8 *>(hbuf + cur + (2 * half) * kHKStride + rd_off);
+            x1 = *reinterpret_cast<const half8 *>(hbuf + cur + (2 * half + 1) * kHKStride + rd_off);
+        }
+    };
     auto spl_step = [&](int step, int p, int cur, int nxt) {
         const unsigned done = (unsigned)(step - s0);     // steps every wave has to have published before this one
         auto rows = [&](const floatx4 &v, int q) {
             if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
         };
-        auto rd = [&](int ks) { return *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off); };
         float hn[NQ];
-        if constexpr (CELL == 0) {
+        if constexpr (CELL == 0 && ZL) {
+            floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
+            if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }
+            half8 a0, a1, a2, a3;
+            wait_read(0, done, cur, a0, a1);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) { ar = mfma16(a0, wf[0][0][sp], ar); az = mfma16(a0, wf[0][1][sp], az); }
+            anh = mfma16(a0, wf[0][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a0, wf[0][2][1], anl);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) { ar = mfma16(a1, wf[1][0][sp], ar); az = mfma16(a1, wf[1][1][sp], az); }
+            anh = mfma16(a1, wf[1][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a1, wf[1][2][1], anl);
+            refill((p + PF - 1) % PF, (step + PF) < s_end);
+            wait_read(1, done, cur, a2, a3);
+            // second half: r and n tiles first ...
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) ar = mfma16(a2, wf[2][0][sp], ar);
+            anh = mfma16(a2, wf[2][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a2, wf[2][2][1], anl);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) ar = mfma16(a3, wf[3][0][sp], ar);
+            anh = mfma16(a3, wf[3][2][0], anh);
+            if constexpr (!HP) anl = mfma16(a3, wf[3][2][1], anl);
+            __builtin_amdgcn_sched_barrier(0);
+            // ... then the z tile, with sigmoid(r), tanh and (h_prev - n) under its MFMAs
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) az = mfma16(a2, wf[2][1][sp], az);
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) az = mfma16(a3, wf[3][1][sp], az);
+            float nn[NQ], dd[NQ], gzv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float gr, gnv;
+                if constexpr (XIN) { gr = 0.f; gzv[q] = 0.f; gnv = rows(gin, q); }
+                else { gr = gq[p][q * NG]; gzv[q] = gq[p][q * NG + 1]; gnv = gq[p][q * NG + 2]; }
+                const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                float tn;
+                if constexpr (HP) tn = anh[q] + bhn;
+                else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                const float an = __builtin_fmaf(rr, tn, gnv);
+                const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                nn[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                dd[q] = hprev[q] - nn[q];
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * NQ + 1, 0);       // VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float tz = XIN ? rows(az, q) : (gzv[q] + rows(az, q));
+                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+                const float h = __builtin_fmaf(zz, dd[q], nn[q]);
+                hprev[q] = h;
+                hn[q] = h;
+            }
+        } else if constexpr (CELL == 0) {
             floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
             if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
             // ---- first half of K: units of waves 0..3
-            wait_half(0, done);
-            const half8 a0 = rd(0), a1 = rd(1);
+            half8 a0, a1, a2, a3;
+            wait_read(0, done, cur, a0, a1);
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) {
                 ar = mfma16(a0, wf[0][0][sp], ar);
@@ -302,8 +392,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             // refill the ring slot consumed in the PREVIOUS step; unconditional, in ring order
             refill((p + PF - 1) % PF, (step + PF) < s_end);
             // ---- second half of K: units of waves 4..7 (their gate math ran under the MFMAs above)
-            wait_half(1, done);
-            const half8 a2 = rd(2), a3 = rd(3);
+            wait_read(1, done, cur, a2, a3);
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) {
                 ar = mfma16(a2, wf[2][0][sp], ar);
@@ -352,8 +441,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             // ---- LSTM cell: all four gate tiles over the first half of K, then i, f, g over the second
             // half and the o tile last with the cell update under its MFMAs
             floatx4 ai = floatx4{0.f, 0.f, 0.f, 0.f}, af = ai, ag = ai, ao = ai;
-            wait_half(0, done);
-            const half8 a0 = rd(0), a1 = rd(1);
+            half8 a0, a1, a2, a3;
+            wait_read(0, done, cur, a0, a1);
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) {
                 ai = mfma16(a0, wf[0][0][sp], ai);
@@ -369,8 +458,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 ao = mfma16(a1, wf[1][3][sp], ao);
             }
             refill((p + PF - 1) % PF, (step + PF) < s_end);
-            wait_half(1, done);
-            const half8 a2 = rd(2), a3 = rd(3);
+            wait_read(1, done, cur, a2, a3);
 #pragma unroll
             for (int sp = 0; sp < NS; ++sp) {
                 ai = mfma16(a2, wf[2][0][sp], ai);
@@ -459,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 stamp(0);   // refill issue + loop overhead
 
                 half8 a[4];
-                if constexpr (SPL) {
+                if constexpr (SPL != 0) {
                     spl_step(step, p, cur, nxt);
                     continue;
                 }
@@ -473,7 +561,57 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
                 };
                 float hn[NQ];
-                if constexpr (CELL == 0) {
+                if constexpr (CELL == 0 && ZL) {
+                    static_assert(!(ZL && ABL), "ablation builds use the n-last order");
+                    floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
+                    if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
+                    // phase 1: r and n tiles
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp) ar = mfma16(a[ks], wf[ks][0][sp], ar);
+                        anh = mfma16(a[ks], wf[ks][2][0], anh);
+                        if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
+                    }
+                    refill((p + PF - 1) % PF, (step + PF) < s_end);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // phase 2: z tile; sigmoid(r), tanh and (h_prev - n) are interleaved with its MFMAs
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp) az = mfma16(a[ks], wf[ks][1][sp], az);
+                    float nn[NQ], dd[NQ], gzv[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float gr, gnv;
+                        if constexpr (XIN) { gr = 0.f; gzv[q] = 0.f; gnv = rows(gin, q); }
+                        else { gr = gq[p][q * NG]; gzv[q] = gq[p][q * NG + 1]; gnv = gq[p][q * NG + 2]; }
+                        const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
+                        const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                        float tn;
+                        if constexpr (HP) tn = anh[q] + bhn;
+                        else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                        const float an = __builtin_fmaf(rr, tn, gnv);
+                        const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                        nn[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                        dd[q] = hprev[q] - nn[q];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4 * NS; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2 * NQ + 1, 0);   // VALU
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float tz = XIN ? rows(az, q) : (gzv[q] + rows(az, q));
+                        const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+                        const float h = __builtin_fmaf(zz, dd[q], nn[q]);
+                        hprev[q] = h;
+                        hn[q] = h;
+                        if (step < s_end) op[q][0] = h;
+                    }
+                } else if constexpr (CELL == 0) {
                     floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
                     if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
                     if constexpr (ABL & 1) {

@@ -54,6 +54,12 @@ struct mdk_rl {
     int opt_force_wt = 0;        // wide model: always use write-through granules (test hook)
     int opt_wide_groups = 0;     // wide model: groups per cluster, 0 = auto
     int opt_poll_delay = 7;      // wide model, one group per cluster: 64-clock sleeps before the first poll
+    int opt_async = 0;           // wide model: 1 = mdk_rl_forward_dev does not synchronise (no retry; see mdk_rl_check)
+    int n_cus = 0;
+    int wide_retries = 0;        // forwards that were re-run on the plain schedule after a time-out
+    bool timing = false;         // hipEvent timing of the front end and of the whole forward (adds a sync)
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // forward start, front start, front end, forward end
+    mdk_rl_timing last{};
     // front end
     float *base_emb = nullptr, *strand_emb = nullptr, *w1 = nullptr, *b1 = nullptr, *a1 = nullptr, *c1 = nullptr;
     half8 *w2frag = nullptr;
@@ -70,7 +76,7 @@ struct mdk_rl {
     hipStream_t side = nullptr;               // next layer's projection under this layer's recurrence
     std::vector<hipEvent_t> ov_ev;
     int opt_overlap = 1;
-    int opt_split_sync = 1;   // lstm_size 128 recurrence: per-wave flags + half-K waits (rec_mfma.hpp SPL)
+    int opt_split_sync = 0;   // lstm_size 128 recurrence: per-wave flags + half-K waits (rec_mfma.hpp SPL)
     std::vector<LstmLayer> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace
@@ -87,6 +93,7 @@ struct mdk_rl {
 extern "C" void mdk_rl_destroy(mdk_rl *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    for (auto e : m->tev) if (e) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->base_emb, (void *)m->strand_emb, (void *)m->w1, (void *)m->b1, (void *)m->a1,
                     (void *)m->c1, (void *)m->w2frag, (void *)m->b2, (void *)m->a2,
                     (void *)m->c2, (void *)m->lin_w, (void *)m->lin_b, (void *)m->mask,
@@ -394,6 +401,8 @@ extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
         if (value != 0 && value != 4 && value != 8 && value != 16)
             return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
         m->opt_tile_windows = value;
+    } else if (!strcmp(key, "wide_async")) {
+        m->opt_async = value ? 1 : 0;
     } else if (!strcmp(key, "split_sync")) {
         m->opt_split_sync = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
@@ -431,9 +440,10 @@ static int rl_workspace(mdk_rl *m, int B, int Dp, size_t rows) {
 }
 
 // lstm_size = 384: front end (pool-only) -> 4 x [k_gemm_rows -> k_lstm_wide] -> head, natural layouts
-static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
-                           float *probs_dev, hipStream_t s) {
+static int rl_forward_wide_once(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                                float *probs_dev, hipStream_t s, bool allow_overlap, int *timed_out) {
     const size_t rows = (size_t)B * P;
+    *timed_out = 0;
     if ((size_t)B * Dp > m->mask_cap) {
         free_dev(m->mask); m->mask = nullptr; m->mask_cap = 0;
         HIP_TRY(hipMalloc((void **)&m->mask, (size_t)B * Dp * sizeof(int)));
@@ -454,7 +464,13 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
         HIP_TRY(hipMalloc((void **)&m->cstate, (size_t)B * kWH * sizeof(float)));
         m->cstate_cap = (size_t)B * kWH;
     }
-    if (!m->side) HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    if (!m->side) {
+        // lowest priority: a projection GEMM that becomes ready together with the next recurrence chunk must
+        // not take CUs before all 12 members of every cluster are resident (they spin on each other)
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo));
+    }
     constexpr int kChunks = 8;
     while (m->ov_ev.size() < kChunks + 1) {
         hipEvent_t e;
@@ -470,8 +486,10 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
     fa.s1 = m->s1; fa.inv2 = m->inv2;
     const bool hp = (m->precision == MDK_PREC_FP16);
+    if (m->timing) HIP_TRY(hipEventRecord(m->tev[1], s));
     if (hp) hipLaunchKernelGGL((k_rl_front<false, true>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
     else hipLaunchKernelGGL((k_rl_front<false, false>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    if (m->timing) HIP_TRY(hipEventRecord(m->tev[2], s));
 
     // groups of 8 windows (16 in half precision); up to 16 groups: one per cluster; more: two interleaved
     const int gw = hp ? 2 * kWWin : kWWin;
@@ -486,7 +504,16 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
     // chunk, the next layer's k_gemm_rows for the columns just produced runs on a side stream, on the
     // >= 64 CUs the clusters never occupy.  (The next recurrence scans the other way and still has
     // to wait for the whole layer.)  Projections alternate between two gi buffers.
-    const bool ovl = m->opt_overlap && P >= 1024;
+    // co-residency: one 512-thread work-group per CU (launch bounds), so the grid must fit the CUs
+    if (m->n_cus == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, m->device));
+        m->n_cus = prop.multiProcessorCount;
+    }
+    if ((int)rec_grid > m->n_cus)
+        return fail(MDK_ERR_DEVICE, "the LSTM(384) cluster recurrence needs %u co-resident work-groups, the device has %d CUs",
+                    rec_grid, m->n_cus);
+    const bool ovl = allow_overlap && m->opt_overlap && P >= 1024;
     const int n_chunks = ovl ? kChunks : 1;
     auto launch_gemm = [&](const WideLayer &Lg, const float *src, float *gi_out, hipStream_t st, int t_begin, int t_len) {
         if (t_len <= 0) return;
@@ -554,19 +581,88 @@ static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, 
                            probs_dev, (long)rows, m->desc.normalise);
     }
     HIP_TRY(hipGetLastError());
-    // the cluster recurrence spins across work-groups with bounded waits: surface a time-out loudly
+    if (m->opt_async) return MDK_OK;        // status is read by the next call or by mdk_rl_check()
+    // the cluster recurrence spins across work-groups with bounded waits: read the time-out flag
     int st = 0;
     HIP_TRY(hipMemcpyAsync(&st, m->status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (st != 0) {
         HIP_TRY(hipMemsetAsync(m->status, 0, sizeof(int), s));
-        return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out (is another kernel occupying the GPU's CUs?)");
+        *timed_out = 1;
     }
+    return MDK_OK;
+}
+
+// The cluster exchange needs every member of a cluster on a CU at the same time.  A time-out (a late
+// member: another tenant on the GPU, or the side-stream projection competing for CUs) is not an error
+// yet: the layer stack is run once more on the plain schedule -- nothing on the side stream, one launch
+// per layer -- and only a second time-out is reported.
+static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                           float *probs_dev, hipStream_t s) {
+    int timed_out = 0;
+    int rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, true, &timed_out);
+    if (rc || !timed_out) return rc;
+    m->wide_retries++;
+    rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, false, &timed_out);
+    if (rc) return rc;
+    if (timed_out)
+        return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out twice (the second time without the "
+                                    "overlapped projection): the rl_lstm384 path needs %d CUs of the GPU to itself",
+                    8 * kWC * 2);
+    return MDK_OK;
+}
+
+// asynchronous mode ("wide_async" = 1): surfaces a time-out of an earlier mdk_rl_forward_dev
+extern "C" int mdk_rl_check(mdk_rl *m, void *stream) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (!m->wide || !m->status) return MDK_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, m->status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (st != 0) {
+        HIP_TRY(hipMemsetAsync(m->status, 0, sizeof(int), (hipStream_t)stream));
+        return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out in an earlier asynchronous forward");
+    }
+    return MDK_OK;
+}
+
+static int rl_forward_dev_inner(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                                float *probs_dev, void *stream);
+
+extern "C" int mdk_rl_enable_timing(mdk_rl *m, int on) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    if (on && !m->tev[0])
+        for (auto &e : m->tev) HIP_TRY(hipEventCreate(&e));
+    m->timing = on != 0;
+    return MDK_OK;
+}
+extern "C" int mdk_rl_get_timing(mdk_rl *m, mdk_rl_timing *out) {
+    if (!m || !out) return fail(MDK_ERR_ARG, "null argument");
+    *out = m->last;
+    out->wide_retries = m->wide_retries;
     return MDK_OK;
 }
 
 extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
                                   float *probs_dev, void *stream) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (!m->timing || B <= 0 || P <= 0) return rl_forward_dev_inner(m, x_dev, B, P, Dp, F, probs_dev, stream);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(m->tev[0], s));
+    int rc = rl_forward_dev_inner(m, x_dev, B, P, Dp, F, probs_dev, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(m->tev[3], s));
+    HIP_TRY(hipEventSynchronize(m->tev[3]));
+    HIP_TRY(hipEventElapsedTime(&m->last.front_ms, m->tev[1], m->tev[2]));
+    HIP_TRY(hipEventElapsedTime(&m->last.total_ms, m->tev[0], m->tev[3]));
+    return MDK_OK;
+}
+
+static int rl_forward_dev_inner(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
+                                float *probs_dev, void *stream) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (B < 0 || P < 0 || Dp < 0) return fail(MDK_ERR_ARG, "negative shape");
     if (B == 0 || P == 0) return MDK_OK;
@@ -593,8 +689,10 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
     fa.c2 = m->c2; fa.pooled = m->act[0];
     fa.B = B; fa.P = P; fa.Dp = Dp; fa.F = F; fa.nf = m->nf; fa.n_alpha = m->desc.alphabet_size;
     fa.s1 = m->s1; fa.inv2 = m->inv2;
+    if (m->timing) HIP_TRY(hipEventRecord(m->tev[1], s));
     if (hp) hipLaunchKernelGGL((k_rl_front<true, true>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
     else hipLaunchKernelGGL((k_rl_front<true, false>), dim3((P + kRlPos - 1) / kRlPos, B), dim3(256), 0, s, fa);
+    if (m->timing) HIP_TRY(hipEventRecord(m->tev[2], s));
 
     // ---- LSTM stack
     const int n_win = n_tiles * kTileWin;
@@ -621,7 +719,7 @@ extern "C" int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, 
     hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, false, HPF, 1, 0, SPLV>), rgrid, dim3(512), 0, s, m->gi, \
                        (const half8 *)nullptr, (const half8 *)nullptr, Ld.whh_frag, Ld.bias, outp, n_tiles, T, D, \
                        Ld.inv_rec, Ld.reverse_mask, (const int *)nullptr, 0, 0, T)
-#define MDK_REC(NQV, HPF) do { if (m->opt_split_sync) MDK_REC_S(NQV, HPF, true); else MDK_REC_S(NQV, HPF, false); } while (0)
+#define MDK_REC(NQV, HPF) do { if (m->opt_split_sync) MDK_REC_S(NQV, HPF, 2); else MDK_REC_S(NQV, HPF, 0); } while (0)
         if (hp) { if (nq == 1) MDK_REC(1, true); else if (nq == 2) MDK_REC(2, true); else MDK_REC(4, true); }
         else { if (nq == 1) MDK_REC(1, false); else MDK_REC(2, false); }
 #undef MDK_REC

@@ -154,6 +154,12 @@ class GruEngine:
         """Raw pileup counts (B,T,F) uint16 + per-column depth (B,T) uint32 -> probabilities and/or
         (argmax class uint8, its probability float32): normalisation (features.py:907-911) and
         argmax decode (labels.py:1061-1065) run on the device."""
+        counts = np.asarray(counts)
+        if counts.dtype != np.uint16:
+            # the reference's counts are size_t (src/medaka_counts.c); the device path carries uint16
+            if counts.size and (counts.max() > 65535 or counts.min() < 0):
+                raise ValueError("pileup counts beyond 65535 do not fit the uint16 device path: normalise on the "
+                                 "host (predict_on_batch) for pileups this deep")
         counts = np.ascontiguousarray(counts, dtype=np.uint16)
         depth = np.ascontiguousarray(depth, dtype=np.uint32)
         if counts.ndim != 3 or counts.shape[2] != self.num_features or depth.shape != counts.shape[:2]:
@@ -223,18 +229,42 @@ class RlEngine:
     """Read-level model (reference LatentSpaceLSTM.forward, latent_space_lstm.py:154-207)."""
 
     def __init__(self, state, use_dwells=False, bidirectional=True, lstm_size=128, cnn_size=128,
-                 kernel_sizes=(1, 17), alphabet_size=6, embedding_size=6, normalise=True, device=0):
+                 kernel_sizes=(1, 17), alphabet_size=6, embedding_size=6, normalise=True, device=0,
+                 num_classes=5):
         self._h = ctypes.c_void_p()
         keys = rl_state_keys(bidirectional)
         missing = [k for k in keys if k not in state]
         if missing:
             raise KeyError(f"state is missing {missing}")
         arrs = [np.ascontiguousarray(np.asarray(state[k], dtype=np.float32)) for k in keys]
-        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         if len(kernel_sizes) != 2:
             raise ValueError("the engine supports exactly two read-level conv layers")
+        # every tensor against the descriptor: mdk_rl_create reads these sizes from raw pointers
+        nf = embedding_size + (2 if use_dwells else 1)
+        D = 2 if bidirectional else 1
+        want = {"base_embedder.weight": (alphabet_size, embedding_size), "strand_embedder.weight": (3, embedding_size),
+                "read_level_conv.convs.0.weight": (cnn_size, nf, int(kernel_sizes[0])),
+                "read_level_conv.convs.3.weight": (cnn_size, cnn_size, int(kernel_sizes[1])),
+                "pre_pool_expansion_layer.weight": (lstm_size, cnn_size), "pre_pool_expansion_layer.bias": (lstm_size,),
+                "linear.weight": (num_classes, D * lstm_size), "linear.bias": (num_classes,)}
+        for conv, bn in ((0, 2), (3, 5)):
+            want[f"read_level_conv.convs.{conv}.bias"] = (cnn_size,)
+            for n in ("weight", "bias", "running_mean", "running_var"):
+                want[f"read_level_conv.convs.{bn}.{n}"] = (cnn_size,)
+        for k in keys:
+            if ("lstm." in k) and "weight_ih" in k:
+                first = k.endswith("_l0") or k.endswith("_l0_reverse")
+                want[k] = (4 * lstm_size, lstm_size if (first or not bidirectional) else D * lstm_size)
+            elif "lstm." in k and "weight_hh" in k:
+                want[k] = (4 * lstm_size, lstm_size)
+            elif "lstm." in k:
+                want[k] = (4 * lstm_size,)
+        for k, a in zip(keys, arrs):
+            if a.shape != want[k]:
+                raise ValueError(f"{k}: shape {a.shape} != expected {want[k]}")
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         desc = _lib.RlDesc(lstm_size, cnn_size, int(kernel_sizes[0]), int(kernel_sizes[1]), int(use_dwells),
-                           alphabet_size, embedding_size, int(bidirectional), 5, int(normalise))
+                           alphabet_size, embedding_size, int(bidirectional), int(num_classes), int(normalise))
         _lib.check(_lib.load().mdk_rl_create(ctypes.byref(desc), ptrs, len(arrs), device,
                                              ctypes.byref(self._h)), "mdk_rl_create")
         self.use_dwells, self.device = use_dwells, device
@@ -247,6 +277,18 @@ class RlEngine:
 
     def set_option(self, key, value):
         _lib.check(_lib.load().mdk_rl_set_option(self._h, key.encode(), int(value)), "mdk_rl_set_option")
+
+    def enable_timing(self, on=True):
+        _lib.check(_lib.load().mdk_rl_enable_timing(self._h, int(on)), "mdk_rl_enable_timing")
+
+    def timing(self):
+        t = _lib.RlTiming()
+        _lib.check(_lib.load().mdk_rl_get_timing(self._h, ctypes.byref(t)), "mdk_rl_get_timing")
+        return {"front_ms": t.front_ms, "total_ms": t.total_ms, "wide_retries": t.wide_retries}
+
+    def check(self, stream=None):
+        """Asynchronous mode ("wide_async"): raise if an earlier forward's cluster exchange timed out."""
+        _lib.check(_lib.load().mdk_rl_check(self._h, stream), "mdk_rl_check")
 
     def forward_host(self, x):
         """x: (B, P, D, F) uint8 host array -> (B, P, 5) float32 host array."""

@@ -24,6 +24,34 @@ _ORIG = {}
 logger = logging.getLogger("medaka_amd")
 
 
+def _gru_supported(model):
+    """Every limit of mdk_gru_create and of the production kernels (include/medaka_amd.h), so that an
+    unsupported archive keeps the reference model instead of failing at the first forward."""
+    return (getattr(model, "gru_size", None) == 128 and 1 <= getattr(model, "num_features", 10) <= 16
+            and 1 <= getattr(model, "n_layers", 2) <= 4)
+
+
+def _rl_supported(model):
+    lstm_size = getattr(model, "lstm_size", None)
+    return (getattr(model, "cnn_size", None) == 128
+            and (lstm_size == 128 or (lstm_size == 384 and not getattr(model, "bidirectional", True)))
+            and list(getattr(model, "kernel_sizes", [])) == [1, 17]
+            and getattr(model, "bases_embedding_size", 6) == 6 and getattr(model, "bases_alphabet_size", 6) <= 8
+            and getattr(model, "num_classes", 5) == 5 and getattr(model, "pooler_type", "mean") == "mean")
+
+
+def _engine_or_reference(new, reference_model):
+    """Build the C-ABI engine now; anything it rejects keeps the reference model (docstring promise)."""
+    from medaka_amd import lib as _lib
+    try:
+        new.engine()
+    except (_lib.EngineError, ValueError, KeyError) as e:
+        logger.warning("medaka_amd: engine rejected %s (%s), keeping the reference model",
+                       type(reference_model).__name__, e)
+        return reference_model
+    return new
+
+
 def convert(model, device=None):
     """Return an engine-backed equivalent of a reference model, or the model itself."""
     import torch
@@ -35,28 +63,30 @@ def convert(model, device=None):
         return model
     if isinstance(model, (amd_models.GRUModel, amd_models.MajorityVoteModel, amd_models.LatentSpaceLSTM)):
         return model
-    if name == "GRUModel" and getattr(model, "gru_size", None) == 128:
+    if name == "GRUModel" and _gru_supported(model):
         kwargs = model.to_dict()["kwargs"]
         kwargs.pop("time_steps", None)
         kwargs.pop("classify_activation", None)
         new = amd_models.GRUModel(**kwargs)
-        new.load_state_dict(model.state_dict())
+        new.load_state_dict(model.state_dict(), strict=True)      # same parameter names as the reference
         new.normalise = getattr(model, "normalise", True)
         if getattr(model, "half_precision", False):
             new.half()
-        return new.to(dev).eval()
-    lstm_size = getattr(model, "lstm_size", None)
-    if (name == "LatentSpaceLSTM" and getattr(model, "cnn_size", None) == 128
-            and (lstm_size == 128 or (lstm_size == 384 and not getattr(model, "bidirectional", True)))
-            and list(getattr(model, "kernel_sizes", [])) == [1, 17]):
+        return _engine_or_reference(new.to(dev).eval(), model)
+    if name == "LatentSpaceLSTM" and _rl_supported(model):
         kwargs = model.to_dict()["kwargs"]
         kwargs.pop("time_steps", None)
         new = amd_models.LatentSpaceLSTM(**kwargs)
-        new.load_state_dict(model.state_dict(), strict=False)
+        state = {k: v for k, v in model.state_dict().items()
+                 if "num_batches_tracked" not in k and "read_level_conv.expansion_layer" not in k}
+        missing = new.load_state_dict(state, strict=False)
+        if missing.unexpected_keys or any("num_batches_tracked" not in k for k in missing.missing_keys):
+            logger.warning("medaka_amd: state_dict mismatch (%s), keeping the reference model", missing)
+            return model
         new.normalise = getattr(model, "normalise", True)
         if getattr(model, "half_precision", False):
             new.half()
-        return new.to(dev).eval()
+        return _engine_or_reference(new.to(dev).eval(), model)
     if name == "MajorityVoteModel":
         return amd_models.MajorityVoteModel().to(dev).eval()
     logger.info("medaka_amd: %s is not accelerated, keeping the reference model", name)

@@ -28,6 +28,10 @@ class RlDesc(ctypes.Structure):
         "embedding_size", "bidirectional", "num_classes", "normalise")]
 
 
+class RlTiming(ctypes.Structure):
+    _fields_ = [("front_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("wide_retries", ctypes.c_int)]
+
+
 class GruTiming(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_float), ("gi_ms", ctypes.c_float * 4),
                 ("rec_ms", ctypes.c_float * 4), ("head_ms", ctypes.c_float),
@@ -53,6 +57,9 @@ ABI = {
     "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),
     "mdk_rl_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mdk_rl_forward_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mdk_rl_check": (_i, [_vp, _vp]),
+    "mdk_rl_enable_timing": (_i, [_vp, _i]),
+    "mdk_rl_get_timing": (_i, [_vp, ctypes.POINTER(RlTiming)]),
     "mdk_rl_set_precision": (_i, [_vp, _i]),
     "mdk_rl_set_normalise": (_i, [_vp, _i]),
     "mdk_rl_set_option": (_i, [_vp, ctypes.c_char_p, _i]),

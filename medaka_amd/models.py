@@ -342,7 +342,7 @@ class LatentSpaceLSTM(ReadLevelFeaturesModel):
                 state, use_dwells=self.use_dwells, bidirectional=self.bidirectional,
                 lstm_size=self.lstm_size, cnn_size=self.cnn_size, kernel_sizes=self.kernel_sizes,
                 alphabet_size=self.bases_alphabet_size, embedding_size=self.bases_embedding_size,
-                normalise=bool(self.normalise), device=dev_index)
+                normalise=bool(self.normalise), device=dev_index, num_classes=self.num_classes)
             self._engine_key = key
         self._engine.set_precision(self.half_precision)
         self._engine.set_normalise(bool(self.normalise))

@@ -96,3 +96,71 @@ def uniform_windows(n_windows, n_cols, seed=1234):
     """Dense uniform [0,1) windows (timing is data independent for this path)."""
     rng = np.random.default_rng(seed)
     return rng.random((n_windows, n_cols, NUM_FEATURES), dtype=np.float32)
+
+
+# ---- read-level model (reference LatentSpaceLSTM, BASELINE config 4b) -------------------------------
+def synth_reads(B, P, D, use_dwells=False, seed=0, empty_tail=True):
+    """Random read-level features in the reference's layout [base, qual, strand, mapq(, dwell)]
+    (src/medaka_read_matrix.c; strand kept in {0, 1} -- see DESIGN.md on the reference's uint8 cast)."""
+    rng = np.random.default_rng(seed)
+    Fd = 5 if use_dwells else 4
+    x = np.zeros((B, P, D, Fd), dtype=np.uint8)
+    x[..., 0] = rng.integers(0, 6, (B, P, D))
+    x[..., 1] = rng.integers(0, 50, (B, P, D))
+    x[..., 2] = rng.integers(0, 2, (B, P, D))
+    x[..., 3] = rng.integers(0, 61, (B, P, D))
+    if use_dwells:
+        x[..., 4] = rng.integers(0, 30, (B, P, D))
+    if empty_tail:   # padded (empty) reads as Batch.collate produces for shallower windows
+        for b in range(B):
+            n_empty = int(rng.integers(0, max(1, D // 2)))
+            if n_empty:
+                x[b, :, D - n_empty:, :] = 0
+    return x
+
+
+def synth_rl_state(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False, seed=0, lstm_gain=3.0,
+                   head_gain=40.0):
+    """A full `LatentSpaceLSTM.state_dict()` (reference key names and shapes, latent_space_lstm.py:
+    93-150) drawn from a seeded numpy generator: PyTorch-default-like uniform(+-1/sqrt(fan_in)) ranges,
+    non-trivial batch-norm statistics, LSTM weights x `lstm_gain` and head x `head_gain` so that the
+    gates saturate and the output distribution is peaked (max prob ~0.6 on average) without making the recurrence chaotic.  Used where committing the
+    weights themselves would be too large (rl_lstm384 is 20 MB): goldens store only x and y."""
+    rng = np.random.default_rng(seed)
+    nf = 6 + 1 + (1 if use_dwells else 0)
+    H, C = lstm_size, cnn_size
+
+    def uni(shape, fan):
+        b = 1.0 / np.sqrt(fan)
+        return rng.uniform(-b, b, shape).astype(np.float32)
+
+    st = {"base_embedder.weight": rng.standard_normal((6, 6)).astype(np.float32),
+          "strand_embedder.weight": rng.standard_normal((3, 6)).astype(np.float32)}
+    for conv, bn, cin, k in ((0, 2, nf, 1), (3, 5, C, 17)):
+        st[f"read_level_conv.convs.{conv}.weight"] = uni((C, cin, k), cin * k)
+        st[f"read_level_conv.convs.{conv}.bias"] = uni((C,), cin * k)
+        st[f"read_level_conv.convs.{bn}.weight"] = (rng.random(C) + 0.5).astype(np.float32)
+        st[f"read_level_conv.convs.{bn}.bias"] = (rng.standard_normal(C) * 0.1).astype(np.float32)
+        st[f"read_level_conv.convs.{bn}.running_mean"] = (rng.standard_normal(C) * 0.3).astype(np.float32)
+        st[f"read_level_conv.convs.{bn}.running_var"] = (rng.random(C) + 0.5).astype(np.float32)
+    st["read_level_conv.expansion_layer.weight"] = uni((H, C), C)
+    st["read_level_conv.expansion_layer.bias"] = uni((H,), C)
+    st["pre_pool_expansion_layer.weight"] = uni((H, C), C)
+    st["pre_pool_expansion_layer.bias"] = uni((H,), C)
+    if bidirectional:
+        for layer in range(2):
+            for sfx in ("", "_reverse"):
+                kin = H if layer == 0 else 2 * H
+                st[f"lstm.weight_ih_l{layer}{sfx}"] = uni((4 * H, kin), H) * np.float32(lstm_gain)
+                st[f"lstm.weight_hh_l{layer}{sfx}"] = uni((4 * H, H), H) * np.float32(lstm_gain)
+                st[f"lstm.bias_ih_l{layer}{sfx}"] = uni((4 * H,), H)
+                st[f"lstm.bias_hh_l{layer}{sfx}"] = uni((4 * H,), H)
+    else:
+        for i in range(4):
+            st[f"lstm.{i}.lstm.weight_ih_l0"] = uni((4 * H, H), H) * np.float32(lstm_gain)
+            st[f"lstm.{i}.lstm.weight_hh_l0"] = uni((4 * H, H), H) * np.float32(lstm_gain)
+            st[f"lstm.{i}.lstm.bias_ih_l0"] = uni((4 * H,), H)
+            st[f"lstm.{i}.lstm.bias_hh_l0"] = uni((4 * H,), H)
+    st["linear.weight"] = uni((5, (2 if bidirectional else 1) * H), H) * np.float32(head_gain)
+    st["linear.bias"] = uni((5,), H)
+    return st

@@ -107,6 +107,29 @@ def test_sharded_run_joins_to_the_same_fastq(sgold, model, case):
     _check_qualities(got[3::4], want[3::4])
 
 
+def test_half_precision_end_to_end_identity_rate(sgold, gold, model):
+    """BASELINE config 5: `model.half()` end to end through stitch.  fp16 operands are outside the fp32 parity
+    contract; what is reported and bounded is the consensus identity against the fp32 run (whose FASTQ is the
+    reference's, see above): per-column argmax identity over every sample, and the stitched records."""
+    mh = models.GRUModel()
+    mh.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    mh = mh.to("cuda").eval().half()
+    spec, sources = so.load_case(sgold, "cfg1")
+    run = lambda mm: so.predict(so.contig_regions(sources), _pileups(sources, spec), mm, Batch.collate,
+                                spec["chunk_len"], spec["chunk_ovlp"], spec["batch_size"], spec["bam_chunk"])
+    half, full = run(mh), run(model)
+    same = sum(int((half[k].label_probs.argmax(-1) == full[k].label_probs.argmax(-1)).sum()) for k in full)
+    cols = sum(full[k].size for k in full)
+    dp = max(float(np.abs(half[k].label_probs - full[k].label_probs).max()) for k in full)
+    lengths = {r.ref_name: r.end for r in so.contig_regions(sources)}
+    got, want = so.fastq(half, lengths).split("\n"), str(sgold["cfg1/fastq"]).split("\n")
+    recs_same = sum(a == b for a, b in zip(got[1::4], want[1::4]))
+    print(f"half precision end to end: argmax identity {same / cols:.6f} over {cols} columns, max|dp| {dp:.2e}, "
+          f"{recs_same}/{len(want[1::4])} stitched records identical to the reference's fp32 consensus")
+    assert got[0::4] == want[0::4]
+    assert same / cols >= 0.9995
+
+
 def test_production_loop_shape_bitwise_and_gil(gold, model):
     from medaka_amd import synth
     chunk_len, ovlp, B = 1000, 200, 200

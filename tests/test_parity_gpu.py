@@ -33,12 +33,17 @@ def engines(gold):
         e.close()
 
 
-def _check(out, ref, tol=TOL, what=""):
+def _check(out, ref, tol=TOL, what="", strict_argmax=False):
     assert out.shape == ref.shape, what
     assert np.isfinite(out).all(), what
     err = np.abs(out - ref).max() if out.size else 0.0
     assert err <= tol, f"{what}: max|dp| = {err:.3e}"
-    # argmax identity wherever the reference itself separates top-2 by more than the tolerance
+    if strict_argmax:
+        # trained (confident) weight sets: the consensus must be the reference's on EVERY column
+        assert np.array_equal(out.argmax(-1), ref.argmax(-1)), what
+        return
+    # near-uniform outputs (random-init weights): argmax identity wherever the reference itself separates
+    # top-2 by more than the tolerance
     srt = np.sort(ref, -1)
     clear = (srt[..., -1] - srt[..., -2]) > 2 * tol
     assert (out.argmax(-1) == ref.argmax(-1))[clear].all(), what
@@ -63,9 +68,24 @@ def test_goldens_from_unmodified_reference(gold, engines, exact):
         if exact and x.shape[1] > 2000:
             continue
         out = engines(wname, exact).forward_host(x)
-        _check(out, gold["gru_outputs"][key], what=f"{key} exact={exact}")
+        _check(out, gold["gru_outputs"][key], what=f"{key} exact={exact}", strict_argmax=(wname == "trained"))
         n += 1
     assert n >= 20
+
+
+@pytest.mark.parametrize("name", ["x5", "x1e-3", "range16", "saturated", "bigx"])
+def test_adversarial_weight_sets_vs_reference_goldens(gold, name):
+    """Weight sets built to hurt the fp16 hi+lo split (oracle/make_golden_adversarial.py): outputs of the
+    unmodified reference on a 10 000-column window.  The contract tolerance (1e-4) applies; trained-derived
+    sets must also agree on every argmax."""
+    from oracle.make_golden_adversarial import adversarial_input, adversarial_state
+    adv = np.load(os.path.join(GOLD, "gru_adversarial.npz"))
+    e = engine.GruEngine(adversarial_state(name, gold["weights_init"], gold["weights_trained"]))
+    out = e.forward_host(adversarial_input(name))
+    e.close()
+    err = float(np.abs(out - adv[name]).max())
+    print(f"adversarial {name}: max|dp| = {err:.2e}")
+    _check(out, adv[name], tol=1e-4, what=name, strict_argmax=name in ("range16", "saturated", "bigx"))
 
 
 def test_consensus_string_identical(gold, engines):
@@ -114,6 +134,30 @@ def test_both_tile_sizes_agree_bitwise(gold):
         e.close()
     assert np.array_equal(outs[0], outs[1])
     _check(outs[1], oracle.c_gru_forward(x, weight_set(gold, "x3")), what="8-window tiles")
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+def test_recurrence_schedule_variants_agree_bitwise(gold, half):
+    """Options "split_sync" (per-wave flags + half-K waits instead of a barrier) and "z_last" (z tile issued
+    last) only re-time the recurrence: every accumulator sees its MFMAs in the same order, so the
+    probabilities must be bit-identical, also across tile sizes and a resumed (chunked) layer."""
+    x = synth.counts_windows(13, 2304, seed=77)          # T >= 2048 and % 16 == 0: overlap chunks are used
+    e = engine.GruEngine(weight_set(gold, "trained"))
+    e.set_precision(half)
+    outs = {}
+    for tile in (4, 8):
+        for split in (0, 1, 2):
+            for zl in (0, 1):
+                e.set_option("rec_windows_per_tile", tile)
+                e.set_option("split_sync", split)
+                e.set_option("z_last", zl)
+                outs[(tile, split, zl)] = e.forward_host(x)
+    e.close()
+    base = outs[(4, 0, 0)]
+    for k, v in outs.items():
+        assert np.array_equal(v, base), k
+    if not half:
+        _check(base, oracle.c_gru_forward(x, weight_set(gold, "trained")), what="variants", strict_argmax=True)
 
 
 def test_multi_pass_batches_agree_bitwise(gold):
@@ -417,18 +461,63 @@ def test_read_level_model_api(gold):
     _check(y.cpu().numpy(), ref, what="LatentSpaceLSTM.forward")
 
 
-def test_read_level_model_half_precision():
-    state = dict(np.load(os.path.join(GOLD, "rl_weights_bi.npz")))
-    x = rl_oracle.synth_reads(5, 300, 10, seed=9)
-    ref = rl_oracle.rl_forward(x, state)
-    e = engine.RlEngine(state)
-    e.set_precision(True)      # fp16 LSTM stack; the read-level front end stays in split precision
+def _half_emulation():
+    """Deviation of the reference's own fp16 recipe run on the CPU (fp16 weights + autocast) from its fp32
+    result, per weight set: oracle/make_golden_adversarial.py part 2.  SURVEY.md section 8c: the engine's
+    half mode must stay within 2x of it."""
+    import json
+    return json.load(open(os.path.join(GOLD, "rl_half_emulation.json")))
+
+
+@pytest.mark.parametrize("name", ["bi", "uni", "bi_dwells", "trained"])
+def test_read_level_model_half_precision(name):
+    emu = _half_emulation()[name]
+    wname = "rl_weights_trained.npz" if name == "trained" else f"rl_weights_{name}.npz"
+    kw = RL_CONFIGS["bi" if name == "trained" else name]
+    state = dict(np.load(os.path.join(GOLD, wname)))
+    x = rl_oracle.synth_reads(4, 400, 20, use_dwells=kw.get("use_dwells", False), seed=77)   # the emulation's input
+    ref = rl_oracle.rl_forward(x, state, **kw)
+    e = engine.RlEngine(state, **kw)
+    e.set_precision(True)
     out = e.forward_host(x)
     e.close()
-    assert np.abs(out - ref).max() <= 2e-3
-    srt = np.sort(ref, -1)
-    clear = (srt[..., -1] - srt[..., -2]) > 4e-3
-    assert (out.argmax(-1) == ref.argmax(-1))[clear].all()
+    d = np.abs(out - ref)
+    print(f"rl half {name}: max|dp| {d.max():.2e} (cpu fp16 emulation {emu['max_abs_dp']:.2e}), "
+          f"mean {d.mean():.2e} ({emu['mean_abs_dp']:.2e})")
+    assert d.max() <= 2 * emu["max_abs_dp"] and d.mean() <= 2 * emu["mean_abs_dp"]
+    assert (out.argmax(-1) == ref.argmax(-1)).mean() >= emu["argmax_agreement"] - 1e-3
+
+
+def test_read_level_trained_weights_argmax_identity():
+    """Weights trained by the reference's own process_batch: confident outputs, so identity of the argmax on
+    every position means something (goldens from the unmodified reference)."""
+    state = dict(np.load(os.path.join(GOLD, "rl_weights_trained.npz")))
+    cases = np.load(os.path.join(GOLD, "rl_trained_cases.npz"))
+    e = engine.RlEngine(state)
+    out = e.forward_host(cases["x"])
+    _check(out, cases["y"], what="read-level trained", strict_argmax=True)
+    x = rl_oracle.synth_reads(6, 1500, 30, seed=123)
+    ref = rl_oracle.rl_forward(x, state)
+    assert np.median(ref.max(-1)) > 0.9
+    _check(e.forward_host(x), ref, what="read-level trained, long", strict_argmax=True)
+    e.close()
+
+
+def test_read_level_reverse_strand_byte():
+    """Real BAMs give strand -1 for reverse reads (src/medaka_read_matrix.c); Batch.collate zero-pads into
+    a uint8 array (torch_ext.py:127-140), so it arrives as byte 255.  The reference would index
+    strand_embedder out of range on it; the engine reads the byte as int8 (-1 -> row 0), which is what the
+    reference computes when the features are kept as int8.  Checked against the oracle on int8 input."""
+    state = dict(np.load(os.path.join(GOLD, "rl_weights_bi.npz")))
+    x = rl_oracle.synth_reads(3, 200, 8, seed=41).astype(np.int16)
+    rev = np.random.default_rng(5).random(x.shape[:3]) < 0.5
+    nonempty = x.sum(-1) != 0
+    x[..., 2] = np.where(rev & nonempty, -1, np.where(nonempty, 1, 0))
+    ref = rl_oracle.rl_forward(x.astype(np.int8), state)
+    e = engine.RlEngine(state)
+    out = e.forward_host(x.astype(np.int8).view(np.uint8))
+    e.close()
+    _check(out, ref, what="strand -1 as byte 255")
 
 
 def test_read_level_empty_reads_and_all_empty_window():
@@ -543,11 +632,11 @@ def test_wide_read_level_half_precision(B, P, D, wide_state):
     e.close()
     _check(full, ref, what="rl_lstm384 back to fp32")
     assert np.isfinite(out).all() and np.abs(out.sum(-1) - 1).max() <= 1e-5
-    assert np.abs(out - ref).max() <= 2e-2
-    assert np.abs(out - ref).mean() <= 1e-3
-    srt = np.sort(ref, -1)
-    clear = (srt[..., -1] - srt[..., -2]) > 4e-2
-    assert (out.argmax(-1) == ref.argmax(-1))[clear].all()
+    emu = _half_emulation()["wide"]       # CPU fp16 emulation of the reference on this weight set: 1.0e-2 / 1.3e-3
+    d = np.abs(out - ref)
+    print(f"rl_lstm384 half: max|dp| {d.max():.2e} (emulation {emu['max_abs_dp']:.2e}), mean {d.mean():.2e} ({emu['mean_abs_dp']:.2e})")
+    assert d.max() <= 2 * emu["max_abs_dp"] and d.mean() <= 2 * emu["mean_abs_dp"]
+    assert (out.argmax(-1) == ref.argmax(-1)).mean() >= emu["argmax_agreement"] - 2e-3
 
 
 def test_plain_c_host_runs(tmp_path):
