@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--model", default="gru", choices=["gru", "rl128", "rl384"],
                     help="gru: the headline consensus model; rl128 / rl384: read-level models (BASELINE config 4b)")
     ap.add_argument("--rl-depth", type=int, default=50, help="read-level models: reads per window")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="dry check of the N > 1 path on a 1-GPU box: every rank uses device 0, the timing barrier runs "
+                         "over gloo (RCCL refuses two ranks on one device); the value is NOT a scaling measurement")
+    ap.add_argument("--device-only", action="store_true",
+                    help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
     return ap.parse_args()
 
@@ -254,13 +259,13 @@ def main():
     from medaka_amd import dist, models, synth
 
     log('start')
-    ranks = dist.Ranks()
+    ranks = dist.Ranks(backend="gloo" if args.shared_gpu else None)
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback of the engine")
-    dev = torch.device("cuda", ranks.local_rank)
+    dev = torch.device("cuda", 0 if args.shared_gpu else ranks.local_rank)
     torch.cuda.set_device(dev)
 
     B, T = args.batch, args.chunk_len
@@ -314,6 +319,14 @@ def main():
     cols_per_step = B * T
     value = ranks.world * cols_per_step * args.steps / elapsed
 
+    if args.device_only:
+        if ranks.rank == 0:
+            print(json.dumps({"metric": "pileup columns/sec (consensus bi-GRU inference)", "value": value,
+                              "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
+                              "ms_per_step": 1e3 * elapsed / args.steps, "device_only": True,
+                              "rec_ms_per_step": sum(rec_ms) / args.steps}), flush=True)
+        ranks.close()
+        return
     # host tensor in -> host tensor out (what run_prediction's loop sees), every rank at once
     eng.enable_timing(False)
     from medaka_amd.torch_ext import Batch
@@ -351,7 +364,8 @@ def main():
                    "batch_windows": B, "chunk_len": T, "columns_per_step_per_gpu": cols_per_step,
                    "weights": "tests/golden/weights_trained.npz (reference-trained on synthetic data; "
                               "published model archives are git-LFS stubs offline)",
-                   "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"},
+                   "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"
+                                  + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
             "ms_per_batch_median": 1e3 * h_med, "timed_batches": len(h2h), "warmup": 2,

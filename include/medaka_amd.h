@@ -250,6 +250,8 @@ int mdk_device_synchronize(int device);
 
 /* MFMA fragment-layout / subnormal self-test run on the device (used by the gpu tests). */
 int mdk_selftest_mfma(int device, float *max_abs_err, int *subnormal_preserved);
+/* Test hook: occupy `blocks` CUs with a compute-bound loop of `iters` FMA pairs per lane (synchronous). */
+int mdk_selftest_burn(int device, int blocks, int iters);
 
 const char *mdk_last_error(void);
 const char *mdk_version(void);

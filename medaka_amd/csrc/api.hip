@@ -1033,6 +1033,26 @@ extern "C" int mdk_device_synchronize(int device) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Test hook: keep `blocks` CUs busy with a compute-bound loop (profiles/soak_wide.py uses it as the competing
+// tenant of the LSTM(384) cluster recurrence).  Synchronous.
+__global__ __launch_bounds__(512, 1) void k_burn(float *out, int iters) {
+    float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 0.5f;
+    for (int i = 0; i < iters; ++i) { a = fmaf(a, b, c); c = fmaf(c, b, a); }
+    if (a + c == 12345.678f) out[0] = a;
+}
+extern "C" int mdk_selftest_burn(int device, int blocks, int iters) {
+    if (blocks < 1 || iters < 0) return fail(MDK_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 4));
+    hipLaunchKernelGGL(k_burn, dim3(blocks), dim3(512), 0, nullptr, d, iters);
+    hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MDK_ERR_DEVICE, "burn kernel failed: %s", hipGetErrorString(e));
+    return MDK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // MFMA self-test: D = A(16x32) B(32x16) with the fragment layout the kernels assume, on
 // asymmetric integer data (exact in fp16/fp32), plus an fp16-subnormal operand probe.
 __global__ void k_selftest(const _Float16 *A /*[16][32]*/, const _Float16 *Bm /*[32][16]*/,
