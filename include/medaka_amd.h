@@ -114,8 +114,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
- *   "split_sync"           = 1 | 0                  recurrence: per-wave flags + half-K waits (1) or one
- *                                                   barrier per step (0)
+ *   "deferred_store"       = 1 | 0                  recurrence: h_t leaves for HBM from inside step t+1 (default 1)
+ *   "split_sync"           = 0 | 1 | 2              recurrence schedule experiments (all bit-identical, measured
+ *   "z_last", "packed_write" = 0 | 1                slower or equal on MI355X: DESIGN.md 4.1; default 0)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;

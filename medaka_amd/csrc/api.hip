@@ -83,6 +83,8 @@ struct mdk_gru {
     size_t gi2_rows = 0;
     int opt_overlap = 1;
     int opt_split_sync = 0;                  // recurrence: 0 one barrier per step; 1 / 2 per-wave flags and half-K waits (rec_mfma.hpp SPL)
+    int opt_deferred_store = 1;              // recurrence: HBM store of h_t from inside step t+1 (rec_mfma.hpp DS)
+    int opt_packed_write = 0;                // recurrence: dword LDS stores of lane pairs (rec_mfma.hpp PW)
     int opt_z_last = 0;                      // recurrence: z tile last (rec_mfma.hpp ZL)
     int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
     // timing
@@ -308,6 +310,10 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
     } else if (!strcmp(key, "split_sync")) {
         m->opt_split_sync = value < 0 ? 0 : (value > 2 ? 2 : value);
+    } else if (!strcmp(key, "deferred_store")) {
+        m->opt_deferred_store = value ? 1 : 0;
+    } else if (!strcmp(key, "packed_write")) {
+        m->opt_packed_write = value ? 1 : 0;
     } else if (!strcmp(key, "z_last")) {
         m->opt_z_last = value ? 1 : 0;
     } else if (!strcmp(key, "stream_host")) {
@@ -593,10 +599,18 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         if ((rc = tm.end())) return rc;
         size_t rspan = 0;
         if ((rc = tm.begin(SLOT_REC0 + l, (hipStream_t)-1, &rspan))) return rc;
-#define MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, ZLV, CND, WANT)                                   \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, A, SPLV, ZLV>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+#define MDK_LAUNCH_REC_P(NQV, XIN, HPF, A, SPLV, ZLV, PWV, CND, WANT)                              \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, A, SPLV, ZLV, PWV>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
                        Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
                        reverse_mask, CND, WANT, rs0, rns)
+#define MDK_LAUNCH_REC_D(NQV, XIN, HPF, CND, WANT)                                                 \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, XIN, HPF, 0, 0, 0, false, false, true>), rgrid, dim3(512), 0, s, gi_src, m->xfrag, \
+                       Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
+                       reverse_mask, CND, WANT, rs0, rns)
+#define MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, ZLV, CND, WANT)                                   \
+    do { if ((A) == 0 && (SPLV) == 0 && !(ZLV) && m->opt_deferred_store) MDK_LAUNCH_REC_D(NQV, XIN, HPF, CND, WANT); \
+         else if ((A) == 0 && (SPLV) == 0 && !(ZLV) && !(HPF) && m->opt_packed_write) MDK_LAUNCH_REC_P(NQV, XIN, HPF, 0, 0, false, true, CND, WANT); \
+         else MDK_LAUNCH_REC_P(NQV, XIN, HPF, A, SPLV, ZLV, false, CND, WANT); } while (0)
 #define MDK_LAUNCH_REC_Z(NQV, XIN, HPF, A, SPLV, CND, WANT)                                        \
     do { if ((A) == 0 && m->opt_z_last) MDK_LAUNCH_REC_S(NQV, XIN, HPF, 0, SPLV, true, CND, WANT);  \
          else MDK_LAUNCH_REC_S(NQV, XIN, HPF, A, SPLV, false, CND, WANT); } while (0)
@@ -741,6 +755,8 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
 #undef MDK_LAUNCH_REC
 #undef MDK_LAUNCH_REC_S
 #undef MDK_LAUNCH_REC_Z
+#undef MDK_LAUNCH_REC_P
+#undef MDK_LAUNCH_REC_D
         if ((rc = tm.end_at(rspan))) return rc;
         m->last.rec_launches++;
         in = outp;

@@ -74,7 +74,16 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // sigmoid(z) and the blend h = n + z (h_prev - n) -- 7 dependent VALU operations instead of the 11 of the
 // tanh chain -- because sigmoid(r), tanh and (h_prev - n) run under the z tile's MFMAs.  Every accumulator
 // still receives its MFMAs in the same order, so the results are bit-identical to ZL = false.
-template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, int SPL = 0, bool ZL = false>
+// PW (fp32-parity mode): publish h_t to the LDS image with ONE 4-byte store per (lane, window) instead of two
+// 2-byte stores.  Neighbouring lanes (units c, c+1) sit in the same dword of a row, which makes the 2-byte
+// scatter a 2-way bank conflict on every store (SQ_LDS_BANK_CONFLICT: 128 cycles per work-group and step,
+// profiles/r2_pmc_step.csv).  The lanes of a pair swap their packed {hi, lo} through DPP; the even lane then
+// stores {hi_c, hi_c+1} into the hi row, the odd lane {lo_c-1, lo_c} into the lo row.  Same bytes, same place.
+// DS (GRU, barrier schedule): the HBM store of h_t is deferred to the MFMA phase of step t+1 (h_prev still
+// holds the value), so its address arithmetic and issue leave the tail between the last MFMA and the LDS
+// publish.  Ablations (profiles/r2_ablation.txt): the stores cost ~115 cycles of a ~1380-cycle step.
+template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, int SPL = 0, bool ZL = false, bool PW = false,
+          bool DS = false>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -206,6 +215,28 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const int rd_off = g * kHGroupStride + c * 16;
     const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
                        (4 * g) * 16 + (c & 7) * 2;
+    // PW: dword store of a lane pair -- even lanes own the hi row, odd lanes the lo row
+    const int wr_pk = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
+                      (4 * g + (c & 1)) * 16 + (c & 6) * 2;
+    const unsigned pk_sel = (c & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 of {neighbour : self}
+    auto publish = [&](const float (&hv)[NQ], int nxt) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            _Float16 hi, lo;
+            split_f16(hv[q] * kActScale, hi, lo);
+            if constexpr (HP) {
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
+            } else if constexpr (PW) {
+                const unsigned self = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                      ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)self, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                *reinterpret_cast<unsigned *>(hbuf + nxt + wr_pk + (2 * q) * 16) = __builtin_amdgcn_perm(nb, self, pk_sel);
+            } else {
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+            }
+        }
+    };
 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -504,17 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         }
         // ---- publish h: the fp16 image for the next step first (that is what the other waves wait for),
         // then the flag, then the HBM store of the layer output
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            _Float16 hi, lo;
-            split_f16(hn[q] * kActScale, hi, lo);
-            if constexpr (HP) {
-                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
-            } else {
-                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
-                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
-            }
-        }
+        publish(hn, nxt);
         asm volatile("ds_write_b32 %0, %1" ::"v"(flag_off + 4u * (unsigned)w8), "v"(done + 1u) : "memory");
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -633,6 +654,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     // refill the ring slot consumed in the PREVIOUS step (data of step + PF - 1): the
                     // vector-memory issue hides under the MFMAs; unconditional, in ring order
                     refill((p + PF - 1) % PF, (step + PF) < s_end);
+                    if constexpr (DS) {
+                        static_assert(!(DS && (ABL || CELL)), "deferred stores: GRU production builds only");
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (step > s0 && step <= s_end) *(op[q] - ostride) = hprev[q];   // h of the previous step
+                    }
                     // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
                     // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
                     // with them (1 MFMA : 2 VALU), so only the tanh/blend/split chain of n is exposed
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
                         hprev[q] = h;
                         hn[q] = h;
-                        if constexpr (!(ABL & 16)) { if (step < s_end) op[q][0] = h; }
+                        if constexpr (!(ABL & 16) && !DS) { if (step < s_end) op[q][0] = h; }
                     }
                 } else {
                     // ---- LSTM cell: i, f, g tiles first; the o tile last, with the cell update
@@ -735,18 +762,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     }
                 }
                 if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain
+                publish(hn, nxt);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    _Float16 hi, lo;
-                    split_f16(hn[q] * kActScale, hi, lo);
-                    if constexpr (HP) {
-                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
-                    } else {
-                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
-                        *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
-                    }
-                    op[q] += ostride;
-                }
+                for (int q = 0; q < NQ; ++q) op[q] += ostride;
                 if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(4); }   // split + LDS write
                 if constexpr (XIN && !(ABL & 1)) {
                     // layer-0 input projection of the NEXT step: independent of h, so it is
@@ -767,6 +785,13 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 lds_barrier();
                 stamp(5);   // barrier wait
             }
+        }
+    }
+    if constexpr (DS) {
+        // the loop runs whole groups of PF steps: when the last of them is step s_end - 1 nobody stored it yet
+        if ((s_end - s0) % PF == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) *(op[q] - ostride) = hprev[q];
         }
     }
     if constexpr (ABL & 64) {

@@ -152,6 +152,14 @@ def test_recurrence_schedule_variants_agree_bitwise(gold, half):
                 e.set_option("split_sync", split)
                 e.set_option("z_last", zl)
                 outs[(tile, split, zl)] = e.forward_host(x)
+        e.set_option("split_sync", 0)
+        e.set_option("z_last", 0)
+        e.set_option("packed_write", 1)          # dword LDS stores of lane pairs: same bytes in the same place
+        outs[(tile, "packed")] = e.forward_host(x)
+        e.set_option("packed_write", 0)
+        e.set_option("deferred_store", 1)        # h_t leaves for HBM from inside step t+1
+        outs[(tile, "deferred")] = e.forward_host(x)
+        e.set_option("deferred_store", 0)
     e.close()
     base = outs[(4, 0, 0)]
     for k, v in outs.items():
