@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
     ap.add_argument("--split-sync", type=int, default=0, help="recurrence: per-wave flags + half-K waits (1) or one barrier per step (0)")
+    ap.add_argument("--rec-waves", type=int, default=None, help="recurrence work-group: 8 waves x 16 units or 4 waves x 32 units")
     ap.add_argument("--deferred-store", type=int, default=None, help="recurrence: store h_t from inside step t+1")
     ap.add_argument("--packed-write", type=int, default=None, help="recurrence: dword LDS stores of lane pairs")
     ap.add_argument("--z-last", type=int, default=None, help="recurrence: z tile last (engine default if omitted)")
@@ -293,6 +294,8 @@ def main():
     eng.set_option("split_sync", args.split_sync)
     if args.z_last is not None:
         eng.set_option("z_last", args.z_last)
+    if args.rec_waves is not None:
+        eng.set_option("rec_waves", args.rec_waves)
     if args.deferred_store is not None:
         eng.set_option("deferred_store", args.deferred_store)
     if args.packed_write is not None:

@@ -19,6 +19,7 @@
 #include "layout.hpp"
 #include "head.hpp"
 #include "rec_mfma.hpp"
+#include "rec_gru4.hpp"
 
 using namespace mdk;
 
@@ -83,6 +84,7 @@ struct mdk_gru {
     size_t gi2_rows = 0;
     int opt_overlap = 1;
     int opt_split_sync = 0;                  // recurrence: 0 one barrier per step; 1 / 2 per-wave flags and half-K waits (rec_mfma.hpp SPL)
+    int opt_rec_waves = 8;                   // recurrence work-group: 8 waves x 16 units (rec_mfma.hpp) or 4 waves x 32 (rec_gru4.hpp)
     int opt_deferred_store = 1;              // recurrence: HBM store of h_t from inside step t+1 (rec_mfma.hpp DS)
     int opt_packed_write = 0;                // recurrence: dword LDS stores of lane pairs (rec_mfma.hpp PW)
     int opt_z_last = 0;                      // recurrence: z tile last (rec_mfma.hpp ZL)
@@ -310,6 +312,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
     } else if (!strcmp(key, "split_sync")) {
         m->opt_split_sync = value < 0 ? 0 : (value > 2 ? 2 : value);
+    } else if (!strcmp(key, "rec_waves")) {
+        if (value != 4 && value != 8) return fail(MDK_ERR_ARG, "rec_waves must be 4 or 8");
+        m->opt_rec_waves = value;
     } else if (!strcmp(key, "deferred_store")) {
         m->opt_deferred_store = value ? 1 : 0;
     } else if (!strcmp(key, "packed_write")) {
@@ -618,8 +623,23 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     do { if ((A) == 0 && m->opt_split_sync == 1) MDK_LAUNCH_REC_Z(NQV, XIN, HPF, 0, 1, CND, WANT);   \
          else if ((A) == 0 && m->opt_split_sync == 2) MDK_LAUNCH_REC_Z(NQV, XIN, HPF, 0, 2, CND, WANT); \
          else MDK_LAUNCH_REC_Z(NQV, XIN, HPF, A, 0, CND, WANT); } while (0)
+#define MDK_LAUNCH_REC4(NQV, XIN, HPF, CND, WANT)                                                  \
+    hipLaunchKernelGGL((k_rec_gru4<MDK_PF, NQV, XIN, HPF>), rgrid, dim3(256), 0, s, gi_src, m->xfrag, \
+                       Ld.wx_frag, Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec,    \
+                       reverse_mask, CND, WANT, rs0, rns)
         // production instantiations
         auto launch = [&](bool xin, const int *cnd, int want) {
+            if (m->opt_rec_waves == 4) {      // one wave per SIMD, 32 units each (rec_gru4.hpp)
+                if (hp) {
+                    if (nq == 1) { if (xin) MDK_LAUNCH_REC4(1, true, true, cnd, want); else MDK_LAUNCH_REC4(1, false, true, cnd, want); }
+                    else if (nq == 2) { if (xin) MDK_LAUNCH_REC4(2, true, true, cnd, want); else MDK_LAUNCH_REC4(2, false, true, cnd, want); }
+                    else { if (xin) MDK_LAUNCH_REC4(4, true, true, cnd, want); else MDK_LAUNCH_REC4(4, false, true, cnd, want); }
+                } else {
+                    if (nq == 1) { if (xin) MDK_LAUNCH_REC4(1, true, false, cnd, want); else MDK_LAUNCH_REC4(1, false, false, cnd, want); }
+                    else { if (xin) MDK_LAUNCH_REC4(2, true, false, cnd, want); else MDK_LAUNCH_REC4(2, false, false, cnd, want); }
+                }
+                return;
+            }
             if (hp) {
                 if (nq == 1) { if (xin) MDK_LAUNCH_REC(1, true, true, 0, cnd, want); else MDK_LAUNCH_REC(1, false, true, 0, cnd, want); }
                 else if (nq == 2) { if (xin) MDK_LAUNCH_REC(2, true, true, 0, cnd, want); else MDK_LAUNCH_REC(2, false, true, 0, cnd, want); }
@@ -757,6 +777,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
 #undef MDK_LAUNCH_REC_Z
 #undef MDK_LAUNCH_REC_P
 #undef MDK_LAUNCH_REC_D
+#undef MDK_LAUNCH_REC4
         if ((rc = tm.end_at(rspan))) return rc;
         m->last.rec_launches++;
         in = outp;

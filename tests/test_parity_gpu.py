@@ -160,6 +160,9 @@ def test_recurrence_schedule_variants_agree_bitwise(gold, half):
         e.set_option("deferred_store", 1)        # h_t leaves for HBM from inside step t+1
         outs[(tile, "deferred")] = e.forward_host(x)
         e.set_option("deferred_store", 0)
+        e.set_option("rec_waves", 4)             # one wave per SIMD owning 32 units (rec_gru4.hpp)
+        outs[(tile, "four waves")] = e.forward_host(x)
+        e.set_option("rec_waves", 8)
     e.close()
     base = outs[(4, 0, 0)]
     for k, v in outs.items():
@@ -179,6 +182,38 @@ def test_multi_pass_batches_agree_bitwise(gold):
         assert np.array_equal(e.forward_host(x), one), budget
     e.close()
     _check(one, oracle.c_gru_forward(x, weight_set(gold, "x3")), what="multi-pass")
+
+
+def test_streamed_host_path_agrees_bitwise(gold):
+    """mdk_gru_forward copies x in and the probabilities out in time slabs under the recurrences (api.hip,
+    HostIO) when T >= 2048 and T % 16 == 0: same bits as one copy each side ("stream_host" = 0), as the
+    device-resident entry, with several passes, with pageable and page-locked buffers, and when the input
+    range flag sends layer 0 down its unfused fallback after the slabs were already consumed."""
+    x = synth.counts_windows(19, 2304, seed=88)
+    e = engine.GruEngine(weight_set(gold, "trained"))
+    streamed = e.forward_host(x)
+    e.set_option("stream_host", 0)
+    plain = e.forward_host(x)
+    e.set_option("stream_host", 1)
+    assert np.array_equal(streamed, plain)
+    e.set_option("max_rows_per_pass", 8 * 2304)                  # 3 passes of 8, 8, 3 windows, each streamed
+    assert np.array_equal(e.forward_host(x), plain)
+    e.set_option("max_rows_per_pass", 0)
+    pin_x, pin_p = engine.PinnedArray(x.shape), engine.PinnedArray(plain.shape)
+    pin_x.array[...] = x
+    assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), plain)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty((19, 2304, 5), dtype=torch.float32, device="cuda")
+    e.forward_ptr(xd.data_ptr(), 19, 2304, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), plain)
+    big = x * np.float32(3000.0)                                   # beyond the fused projection's fp16 range
+    a = e.forward_host(big)
+    e.set_option("stream_host", 0)
+    assert np.array_equal(e.forward_host(big), a)
+    e.close()
+    pin_x.free(); pin_p.free()
+    _check(plain, oracle.c_gru_forward(x, weight_set(gold, "trained")), what="streamed host path", strict_argmax=True)
 
 
 def test_overlapped_projection_agrees_bitwise(gold):
