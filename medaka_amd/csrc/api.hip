@@ -787,7 +787,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
     if (io_out) {
-        if (!head_done) {
+        if (out_ranges.empty()) {      // head not chunked, or its chunks were not streamed: one copy behind it
             HIP_TRY(hipMemcpyAsync(io->p_host, probs, p_bytes, hipMemcpyDeviceToHost, s));
         } else {
             // every kernel of the pass is enqueued: now the copies, each behind its head chunk

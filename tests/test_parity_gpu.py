@@ -216,6 +216,26 @@ def test_streamed_host_path_agrees_bitwise(gold):
     _check(plain, oracle.c_gru_forward(x, weight_set(gold, "trained")), what="streamed host path", strict_argmax=True)
 
 
+def test_host_path_shape_stress(gold):
+    """Back-to-back host calls of changing shape and precision through ONE engine (event pool, staging and
+    workspace reuse, streamed and plain schedules interleaved): each equals the device-resident entry."""
+    rng = np.random.default_rng(2024)
+    e = engine.GruEngine(weight_set(gold, "trained"))
+    shapes = [(1, 13), (3, 2048), (1, 2064), (17, 2304), (2, 4096), (9, 100), (33, 2048), (1, 1), (5, 3008), (40, 2320)]
+    for i in range(24):
+        B, T = shapes[int(rng.integers(len(shapes)))]
+        half = bool(rng.integers(2))
+        e.set_precision(half)
+        x = synth.counts_windows(B, T, seed=int(rng.integers(1 << 30)))
+        host = e.forward_host(x)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.empty((B, T, 5), dtype=torch.float32, device="cuda")
+        e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(host, yd.cpu().numpy()), (i, B, T, half)
+    e.close()
+
+
 def test_overlapped_projection_agrees_bitwise(gold):
     """Layer 0's recurrence in resumable chunks with layer 1's projection GEMM on a side stream
     (api.hip, forward_pass) is the same arithmetic as the plain sequence: identical bits, for the
