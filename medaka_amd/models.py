@@ -369,7 +369,7 @@ class LatentSpaceLSTM(ReadLevelFeaturesModel):
                 raise ValueError(f"expected (B, P, D, F) input, got {tuple(x.shape)}")
             x = x.detach().to(torch.uint8).contiguous()
             B, P, D, F = x.shape
-            out = torch.empty((B, P, 5), dtype=torch.float32)
+            out = _host_output((B, P, 5))          # page-locked, recycled by torch's host allocator
             eng.forward_ptr(x.data_ptr(), B, P, D, F, out.data_ptr(), host=True)
             return out
         return self.forward(x).detach().cpu()
