@@ -44,6 +44,23 @@ __device__ __forceinline__ void split_f16(float xs, _Float16 &hi, _Float16 &lo) 
     lo = (_Float16)(xs - (float)hi);
 }
 
+// N consecutive floats at a 4-byte aligned address as ONE memory instruction (global_load/store_dwordx3/x4
+// only need dword alignment on gfx950).  The vector type is declared with 4-byte alignment so that the
+// compiler neither assumes more nor splits the access.
+template <int N>
+struct FloatRun {
+    typedef float vec_t __attribute__((ext_vector_type(N)));
+    typedef vec_t unaligned_t __attribute__((aligned(4)));
+};
+template <int N>
+__device__ __forceinline__ typename FloatRun<N>::vec_t load_run(const float *p) {
+    return *reinterpret_cast<const typename FloatRun<N>::unaligned_t *>(p);
+}
+template <int N>
+__device__ __forceinline__ void store_run(float *p, typename FloatRun<N>::vec_t v) {
+    *reinterpret_cast<typename FloatRun<N>::unaligned_t *>(p) = v;
+}
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for global loads/stores
 // in flight (the gi prefetch ring and the h stores must stay in flight across steps).
 __device__ __forceinline__ void lds_barrier() {

@@ -18,10 +18,11 @@
 namespace mdk {
 
 // ------------------------------------------------------------------------------------------
-// layer 0.  One 768-thread work-group per (tile, direction, strip of time steps); thread f4 owns
-// float4 number f4 of every 12 KB gi block of its tile = 4 consecutive hidden units of one
-// (w8, q, gate) for window-group g; its 4 x K weights stay in registers; x rows are tiny
-// broadcast loads.  Every block is written as one contiguous 12 KB run.
+// layer 0.  One 768-thread work-group per (tile, direction, strip of time steps); thread f4 owns float4
+// number f4 of every 12 KB gi block of its tile.  With the gate-fastest block order (layout.hpp) the four
+// elements of a float4 are consecutive (lane, gate) pairs, so each has its own (window, unit, gate): their
+// K weights stay in registers, x rows are tiny broadcast loads.  Every block is written as one contiguous
+// 12 KB run.  (Only the unfused / out-of-range fallback path runs this kernel.)
 template <int KMAX>
 __global__ __launch_bounds__(768) void k_gi_small(
     const float *__restrict__ x,      // [B][T][K] natural layout (the reference's batch tensor)
@@ -36,38 +37,40 @@ __global__ __launch_bounds__(768) void k_gi_small(
     const int d = blockIdx.y;
     const float os = out_scale_p[d];
     const int f4 = threadIdx.x;
-    const int c4 = f4 & 3, g = (f4 >> 2) & 3, rest = f4 >> 4;   // rest = (w8*2+q)*3 + gate
-    const int gate = rest % 3, wq = rest / 3, q = wq & 1, w8 = wq >> 1;
-    const int j0 = gate * kH + 16 * w8 + 4 * c4;
-    float4 wreg[KMAX];
+    float wreg[4][KMAX];
+    float b4[4];
+    const float *xw[4];
+    bool real[4];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-        wreg[k] = (k < K) ? *reinterpret_cast<const float4 *>(w_ih_t + ((size_t)d * K + k) * kG + j0)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 b = *reinterpret_cast<const float4 *>(bias + (size_t)d * kG + j0);
-    const int win = tile * kTileWin + 2 * g + q;
-    const bool real = win < B;          // padding windows of the last tile see x = 0
-    const float *xw = x + (size_t)(real ? win : 0) * T * K;
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * f4 + e;                       // element of the block: ((w8*2+q)*64 + lane)*3 + gate
+        const int gate = i % 3, lane = (i / 3) & 63, wq = i / 192;
+        const int q = wq & 1, w8 = wq >> 1;
+        const int j = gate * kH + 16 * w8 + (lane & 15);
+        const int win = tile * kTileWin + 2 * (lane >> 4) + q;
+        real[e] = win < B;                              // padding windows of the last tile see x = 0
+        xw[e] = x + (size_t)(real[e] ? win : 0) * T * K;
+        b4[e] = bias[(size_t)d * kG + j];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) wreg[e][k] = (k < K) ? w_ih_t[((size_t)d * K + k) * kG + j] : 0.f;
+    }
     const int t0 = blockIdx.z * t_per_block;
     const int t1 = min(T, t0 + t_per_block);
     float *gout = gi + gi_block(d, n_tiles, tile, T, t0, 3) + 4 * f4;
     for (int t = t0; t < t1; ++t, gout += gi_block_floats(3)) {
-        const float *xr = xw + (size_t)t * K;
-        float4 acc = b;
-        if (real) {
+        float acc[4];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                if (k < K) {
-                    const float xv = xr[k];
-                    acc.x = fmaf(xv, wreg[k].x, acc.x);
-                    acc.y = fmaf(xv, wreg[k].y, acc.y);
-                    acc.z = fmaf(xv, wreg[k].z, acc.z);
-                    acc.w = fmaf(xv, wreg[k].w, acc.w);
-                }
+        for (int e = 0; e < 4; ++e) {
+            acc[e] = b4[e];
+            if (real[e]) {
+                const float *xr = xw[e] + (size_t)t * K;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) acc[e] = fmaf(xr[k], wreg[e][k], acc[e]);
             }
+            acc[e] *= os;                               // exact: os is a power of two
         }
-        acc.x *= os; acc.y *= os; acc.z *= os; acc.w *= os;   // exact: os is a power of two
-        *reinterpret_cast<float4 *>(gout) = acc;
+        *reinterpret_cast<float4 *>(gout) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -194,8 +197,10 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
                 const int t = t0 + 2 * mt + tt;
                 if (t < T) {
                     float *dst = gblk + (size_t)(2 * mt + tt) * gi_block_floats(NG) + gi_in_block(w8, q, 0, lane, NG);
+                    typename FloatRun<NG>::vec_t v;
 #pragma unroll
-                    for (int nt = 0; nt < NG; ++nt) dst[nt * 64] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
+                    for (int nt = 0; nt < NG; ++nt) v[nt] = fmaf(acc[mt][nt][r], inv_scale, bv[nt]);
+                    store_run<NG>(dst, v);      // the NG gates of (unit, window) are adjacent (layout.hpp)
                 }
             }
         }

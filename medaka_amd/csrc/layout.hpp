@@ -6,7 +6,10 @@
 // layout made each of them four 64-byte runs 15 MB apart, and the kernel was bound by the number
 // of cache lines its vector-memory instructions touched, not by bytes):
 //
-//   gi_t  [dir][tile][t][w8 8][q 2][gate NG][lane 64]  fp32   NG = 3 (GRU): 12 KB per block
+//   gi_t  [dir][tile][t][w8 8][q 2][lane 64][gate NG]  fp32   NG = 3 (GRU): 12 KB per block
+//         (gate fastest: the recurrence reads the NG pre-activations of its (unit, window) with ONE 12- or
+//          16-byte load per lane and the GEMM stores them with one: three dword loads 256 B apart cost 4.4 %
+//          of the recurrence, profiles/r2_ablation.txt mask 32)
 //   act_t [tile][t][dir][w8 8][q 2][lane 64]            fp32   D*1024 floats per block
 //
 // with  lane = g*16 + c,  window-in-tile = 2*g + q,  hidden unit = 16*w8 + c.
@@ -24,7 +27,7 @@ __host__ __device__ inline size_t gi_block(int dir, int n_tiles, int tile, int T
     return (((size_t)dir * n_tiles + tile) * T + t) * gi_block_floats(NG);
 }
 __host__ __device__ inline int gi_in_block(int w8, int q, int gate, int lane, int NG) {
-    return ((w8 * 2 + q) * NG + gate) * 64 + lane;
+    return ((w8 * 2 + q) * 64 + lane) * NG + gate;
 }
 __host__ __device__ inline size_t act_block(int D, int tile, int T, int t) {
     return ((size_t)tile * T + t) * (size_t)(D * 1024);

@@ -111,9 +111,11 @@ __global__ __launch_bounds__(256, 1) void k_rec_gru4(
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    const auto v = load_run<3>(gp[q] + j * kGiTile);
 #pragma unroll
-                    for (int gate = 0; gate < 3; ++gate) gq[p][j][q * 3 + gate] = gp[q][j * kGiTile + gate * 64];
+                    for (int gate = 0; gate < 3; ++gate) gq[p][j][q * 3 + gate] = v[gate];
+                }
                 if (advance) gp[q] += gstride;
             }
         }

@@ -183,9 +183,15 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
+                if constexpr (ABL & 8) {
 #pragma unroll
-                for (int gate = 0; gate < NG; ++gate)
-                    if constexpr (!(ABL & 8)) gq[p][q * NG + gate] = gp[q][gate * 64]; else gq[p][q * NG + gate] = 0.f;
+                    for (int gate = 0; gate < NG; ++gate) gq[p][q * NG + gate] = 0.f;
+                } else {
+                    // one 12-byte (GRU) / 16-byte (LSTM) load: the NG gates of this lane's (unit, window) are adjacent
+                    const auto v = load_run<NG>(gp[q]);
+#pragma unroll
+                    for (int gate = 0; gate < NG; ++gate) gq[p][q * NG + gate] = v[gate];
+                }
                 if (advance) gp[q] += gstride;   // stop advancing at the last row
             }
         }
