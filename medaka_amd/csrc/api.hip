@@ -680,11 +680,16 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             // one phase, or kOvChunks with, behind each on the side stream, what the newly complete columns
             // [T-s', T-s) + [s, s') feed: layer 1's projection (l = 0) or the classifier head (last layer).
             std::vector<int> ph{0};
-            if (slabs) for (int sh = 4; sh >= 2; --sh) ph.push_back((T >> sh) / kGemmSteps * kGemmSteps);
+            if (slabs) for (int sh = (T >= 8192 ? 5 : 4); sh >= 2; --sh) ph.push_back((T >> sh) / kGemmSteps * kGemmSteps);
             ph.push_back(T / 2);
             const int n_first = (int)ph.size() - 1;
-            if (side_gemm || side_head)
+            if (side_gemm) {
                 for (int j = 1; j < kOvChunks; ++j) ph.push_back(T / 2 + (int)((long)(T / 2) * j / kOvChunks) / kGemmSteps * kGemmSteps);
+            } else if (side_head) {
+                // halving chunks: what follows the last recurrence launch (its head chunk, and on the host path
+                // the copy of that chunk) is T/32 columns instead of T/12
+                for (int k = 1; k <= 4; ++k) ph.push_back(T / 2 + ((T / 2) - ((T / 2) >> k)) / kGemmSteps * kGemmSteps);
+            }
             ph.push_back(T);
             const int n_ph = (int)ph.size() - 1;
             size_t gspan = 0;
