@@ -6,9 +6,9 @@ set -u
 OUT=$1; B=$2; R=$PWD
 mkdir -p "$R/$OUT"; export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_b$B" -o pmc -- \
-   python "$R/bench.py" --steps 1 --warmup 0 --cpu-sample 0 --batch $B > "$R/$OUT/pmc_b$B.log" 2>&1
+   python "$R/bench.py" --steps 1 --warmup 0 --cpu-budget 0 --batch $B > "$R/$OUT/pmc_b$B.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/kt_b$B" -o kt -- \
-   python "$R/bench.py" --steps 1 --warmup 0 --cpu-sample 0 --batch $B > "$R/$OUT/kt_b$B.log" 2>&1
+   python "$R/bench.py" --steps 1 --warmup 0 --cpu-budget 0 --batch $B > "$R/$OUT/kt_b$B.log" 2>&1
 cd "$R"
 python - "$OUT" "$B" <<'PY'
 import csv, glob, sys, collections

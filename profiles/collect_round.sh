@@ -5,9 +5,9 @@ set -u
 TAG=${1:-r1_final}; R=$PWD; OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp
 python bench.py > "$OUT/bench_B200.json" 2> "$OUT/bench_B200.log"
-python bench.py --half --cpu-sample 0 > "$OUT/bench_B200_half.json" 2>/dev/null
-python bench.py --batch 1000 --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/bench_B1000.json" 2>/dev/null
-python bench.py --overlap 0 --cpu-sample 0 > "$OUT/bench_B200_no_overlap.json" 2>/dev/null
+python bench.py --half --cpu-budget 0 > "$OUT/bench_B200_half.json" 2>/dev/null
+python bench.py --batch 1000 --steps 3 --warmup 1 --cpu-budget 0 > "$OUT/bench_B1000.json" 2>/dev/null
+python bench.py --overlap 0 --cpu-budget 0 > "$OUT/bench_B200_no_overlap.json" 2>/dev/null
 python profiles/bench_rl.py 100 10000 50 > "$OUT/rl128_B100.json" 2>/dev/null
 python profiles/bench_rl.py 100 10000 50 --half > "$OUT/rl128_B100_half.json" 2>/dev/null
 python profiles/bench_rl.py 100 10000 50 --wide > "$OUT/rl384_B100.json" 2>/dev/null
@@ -15,8 +15,8 @@ python profiles/bench_rl.py 256 10000 50 --wide > "$OUT/rl384_B256.json" 2>/dev/
 python profiles/bench_rl.py 100 10000 50 --wide --half > "$OUT/rl384_B100_half.json" 2>/dev/null
 cd /tmp
 # kernel traces (their own runs; counters below are separate passes)
-rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru" -o gru -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru_no_overlap" -o gru -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 --overlap 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru" -o gru -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-budget 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru_no_overlap" -o gru -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-budget 0 --overlap 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_rl128" -o rl -- python "$R/profiles/bench_rl.py" 100 10000 50 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_rl384" -o rl -- python "$R/profiles/bench_rl.py" 100 10000 50 --wide > /dev/null 2>&1
 cd "$R"

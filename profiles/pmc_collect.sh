@@ -20,7 +20,7 @@ for PASS in \
   "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $PASS --output-format csv -d "$R/$OUT/pass$i" -o pmc -- \
-      python "$R/bench.py" --steps 1 --warmup 0 --cpu-sample 0 "$@" > "$R/$OUT/pass$i.log" 2>&1
+      python "$R/bench.py" --steps 1 --warmup 0 --cpu-budget 0 "$@" > "$R/$OUT/pass$i.log" 2>&1
   echo "pass $i ($PASS) rc=$?"
 done
 cd "$R"
