@@ -366,7 +366,28 @@ def test_full_batch_properties(gold, engines):
     # spot-check windows against the CPU oracle (seconds at this size)
     pick = [0, 77, 199]
     ref = oracle.c_gru_forward(x[pick], gold["weights_trained"])
-    _check(out[pick], ref, what="full batch spot check")
+    _check(out[pick], ref, what="full batch spot check", strict_argmax=True)
+    # time-reversal duality, every one of the 2 M columns: a bidirectional GRU whose forward and reverse
+    # parameters are swapped (and whose layer-1 / linear input halves are swapped with them) maps the reversed
+    # window to the reversed output.  The dual runs every window through the OTHER direction's kernel path and
+    # sums the layer-1 projection and the head in a different order, so this is an independent computation of
+    # the whole batch; it must agree to the parity tolerance and on every argmax the first run is sure of.
+    st = gold["weights_trained"]
+    dual = {}
+    for layer in (0, 1):
+        for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            a, b = st[f"gru.{name}_l{layer}"], st[f"gru.{name}_l{layer}_reverse"]
+            if name == "weight_ih" and layer == 1:
+                a, b = np.concatenate([a[:, 128:], a[:, :128]], 1), np.concatenate([b[:, 128:], b[:, :128]], 1)
+            dual[f"gru.{name}_l{layer}"], dual[f"gru.{name}_l{layer}_reverse"] = b.copy(), a.copy()
+    dual["linear.weight"] = np.concatenate([st["linear.weight"][:, 128:], st["linear.weight"][:, :128]], 1)
+    dual["linear.bias"] = st["linear.bias"].copy()
+    ed = engine.GruEngine(dual)
+    out_d = ed.forward_host(np.ascontiguousarray(x[:, ::-1]))[:, ::-1]
+    ed.close()
+    err = float(np.abs(out_d - out).max())
+    print(f"time-reversal duality over {B * T} columns: max|dp| = {err:.2e}")
+    _check(out_d, out, what="time-reversal duality")
 
 
 def test_model_api_predict_on_batch(gold):
