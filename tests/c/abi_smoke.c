@@ -51,6 +51,27 @@ int main(void) {
         }
         if (fabs(s - 1.0) > worst) worst = fabs(s - 1.0);
     }
+    /* the streamed host path: a window long enough for time slabs (T >= 2048, T % 16 == 0), page-locked buffers
+     * from the ABI; must equal the same call with one copy each side ("stream_host" = 0), bit for bit */
+    {
+        const int T2 = 2304;
+        float *x2 = NULL, *pa = NULL, *pb = NULL;
+        if (mdk_host_alloc((size_t)B * T2 * I * sizeof(float), (void **)&x2) != MDK_OK ||
+            mdk_host_alloc((size_t)B * T2 * 5 * sizeof(float), (void **)&pa) != MDK_OK ||
+            mdk_host_alloc((size_t)B * T2 * 5 * sizeof(float), (void **)&pb) != MDK_OK) {
+            printf("mdk_host_alloc: %s\n", mdk_last_error());
+            return 1;
+        }
+        for (int i = 0; i < B * T2 * I; ++i) x2[i] = frand(&seed) + 0.5f;
+        if (mdk_gru_forward(m, x2, B, T2, pa) != MDK_OK || mdk_gru_set_option(m, "stream_host", 0) != MDK_OK ||
+            mdk_gru_forward(m, x2, B, T2, pb) != MDK_OK || mdk_gru_set_option(m, "stream_host", 1) != MDK_OK) {
+            printf("streamed forward: %s\n", mdk_last_error());
+            return 1;
+        }
+        for (int i = 0; i < B * T2 * 5; ++i)
+            if (pa[i] != pb[i]) { printf("streamed and plain host paths differ at %d\n", i); return 1; }
+        mdk_host_free(x2); mdk_host_free(pa); mdk_host_free(pb);
+    }
     /* argument errors come back as codes + message, never as exit() */
     if (mdk_gru_forward(m, NULL, B, T, p) != MDK_ERR_ARG) { printf("expected MDK_ERR_ARG\n"); return 1; }
     mdk_gru_destroy(m);
