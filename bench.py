@@ -53,11 +53,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
-    ap.add_argument("--split-sync", type=int, default=0, help="recurrence: per-wave flags + half-K waits (1) or one barrier per step (0)")
-    ap.add_argument("--rec-waves", type=int, default=None, help="recurrence work-group: 8 waves x 16 units or 4 waves x 32 units")
     ap.add_argument("--deferred-store", type=int, default=None, help="recurrence: store h_t from inside step t+1")
-    ap.add_argument("--packed-write", type=int, default=None, help="recurrence: dword LDS stores of lane pairs")
-    ap.add_argument("--z-last", type=int, default=None, help="recurrence: z tile last (engine default if omitted)")
     ap.add_argument("--model", default="gru", choices=["gru", "rl128", "rl384"],
                     help="gru: the headline consensus model; rl128 / rl384: read-level models (BASELINE config 4b)")
     ap.add_argument("--rl-depth", type=int, default=50, help="read-level models: reads per window")
@@ -291,15 +287,8 @@ def main():
     eng = model.engine()
     eng.set_option("rec_windows_per_tile", args.tile)
     eng.set_option("overlap_gemm", args.overlap)
-    eng.set_option("split_sync", args.split_sync)
-    if args.z_last is not None:
-        eng.set_option("z_last", args.z_last)
-    if args.rec_waves is not None:
-        eng.set_option("rec_waves", args.rec_waves)
     if args.deferred_store is not None:
         eng.set_option("deferred_store", args.deferred_store)
-    if args.packed_write is not None:
-        eng.set_option("packed_write", args.packed_write)
     eng.enable_timing(True)
 
     out_holder = {}

@@ -115,8 +115,6 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
  *   "deferred_store"       = 1 | 0                  recurrence: h_t leaves for HBM from inside step t+1 (default 1)
- *   "split_sync"           = 0 | 1 | 2              recurrence schedule experiments (all bit-identical, measured
- *   "z_last", "packed_write" = 0 | 1                slower or equal on MI355X: DESIGN.md 4.1; default 0)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
@@ -202,7 +200,6 @@ int mdk_rl_set_normalise(mdk_rl *m, int normalise);
 /* Tuning / test knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8 | 16   lstm_size 128: recurrence work-group granularity
  *   "wide_async"           = 0 | 1                  lstm_size 384: do not synchronise in mdk_rl_forward_dev (see above)
- *   "split_sync"           = 0 | 1                  lstm_size 128: recurrence with per-wave flags + half-K waits
  *   "overlap_gemm"         = 1 | 0                  lstm_size 384: next layer's projection on a side stream
  *                                                   behind resumable recurrence chunks (P >= 1024)
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through

@@ -22,8 +22,6 @@
 
 namespace mdk {
 
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-constexpr int kSplSpinLimit = 1 << 18;       // polls (~100 cycles each) before a wave stops waiting: never a hang
 
 // byte offset of a __shared__ object inside the work-group's LDS allocation
 __device__ __forceinline__ unsigned lds_offset(const void *p) {
@@ -55,35 +53,10 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 // row per window (row 4g + q, up to NQ = 4 -> 16 windows per work-group), 12 MFMAs per wave.
 // CELL: 0 = GRU (3 gate tiles r,z,n), 1 = LSTM (4 gate tiles i,f,g,o; PyTorch nn.LSTM cell, used by
 // the read-level model, reference latent_space_lstm.py:129-149).
-// SPL: split synchronisation instead of one s_barrier per step.  The two waves of a SIMD share its
-// matrix pipe, so the second-dispatched half of the work-group (waves 4..7) runs its 24 MFMAs ~300-400
-// cycles behind the first half (waves 0..3) and, under a barrier, everybody waits for it and then
-// everybody waits again for LDS.  With SPL each wave publishes "my 16 units of step i are in LDS" in a
-// per-wave flag word, and a step consumes the h image in two halves: k-steps 0,1 (units of waves 0..3)
-// as soon as those four flags are up, k-steps 2,3 (waves 4..7) as soon as theirs are.  The early half's
-// next-step MFMAs then run under the late half's gate math and vice versa: the matrix pipe stays busy
-// across the step boundary.  Safety of the double-buffered image: a wave writes h(i+1) into the buffer
-// h(i-1) was read from only after its own step-(i+1) MFMAs, which needed every wave's flag for step i,
-// which each wave raises after its last read of h(i-1).  LDS executes one wave's operations in order,
-// so "h stores, then flag store" needs no wait in between; compiler barriers keep the program order.
-// SPL = 2: the flag read and the two A-fragment reads of a half are issued together (LDS executes a wave's
-// operations in order and the producer stores the data before the flag, so a flag that reads "up" vouches
-// for the fragments read behind it); nothing is added to the critical path when the flag is already up,
-// and a miss sleeps 64 clocks before the retry instead of spinning on the issue port.
-// ZL (GRU): issue the r and n tiles first and the z tile LAST.  What follows the last MFMA is then only
-// sigmoid(z) and the blend h = n + z (h_prev - n) -- 7 dependent VALU operations instead of the 11 of the
-// tanh chain -- because sigmoid(r), tanh and (h_prev - n) run under the z tile's MFMAs.  Every accumulator
-// still receives its MFMAs in the same order, so the results are bit-identical to ZL = false.
-// PW (fp32-parity mode): publish h_t to the LDS image with ONE 4-byte store per (lane, window) instead of two
-// 2-byte stores.  Neighbouring lanes (units c, c+1) sit in the same dword of a row, which makes the 2-byte
-// scatter a 2-way bank conflict on every store (SQ_LDS_BANK_CONFLICT: 128 cycles per work-group and step,
-// profiles/r2_pmc_step.csv).  The lanes of a pair swap their packed {hi, lo} through DPP; the even lane then
-// stores {hi_c, hi_c+1} into the hi row, the odd lane {lo_c-1, lo_c} into the lo row.  Same bytes, same place.
 // DS (GRU, barrier schedule): the HBM store of h_t is deferred to the MFMA phase of step t+1 (h_prev still
 // holds the value), so its address arithmetic and issue leave the tail between the last MFMA and the LDS
 // publish.  Ablations (profiles/r2_ablation.txt): the stores cost ~115 cycles of a ~1380-cycle step.
-template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, int SPL = 0, bool ZL = false, bool PW = false,
-          bool DS = false>
+template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, bool DS = false>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
     const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
@@ -97,7 +70,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                       // s0 > 0 resumes from the h this kernel stored at scan step s0 - 1 (GRU only)
 {
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
-    __shared__ __attribute__((aligned(16))) unsigned int hflag[8];   // SPL: steps completed by wave w8 (0..3 | 4..7)
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
     if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
 
@@ -137,7 +109,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             for (int sp = 0; sp < NS; ++sp) wx[gate][sp] = wp[(size_t)(gate * 2 + sp) * 64];
     }
     for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
-    if (tid < 8) hflag[tid] = 0u;
 
     const int u = 16 * w8 + c;
     const float bhn = CELL ? 0.f : b_hn[d * kH + u] * (1.0f / inv_scale);
@@ -221,10 +192,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const int rd_off = g * kHGroupStride + c * 16;
     const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
                        (4 * g) * 16 + (c & 7) * 2;
-    // PW: dword store of a lane pair -- even lanes own the hi row, odd lanes the lo row
-    const int wr_pk = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride +
-                      (4 * g + (c & 1)) * 16 + (c & 6) * 2;
-    const unsigned pk_sel = (c & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 of {neighbour : self}
     auto publish = [&](const float (&hv)[NQ], int nxt) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -232,11 +199,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
             split_f16(hv[q] * kActScale, hi, lo);
             if constexpr (HP) {
                 *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
-            } else if constexpr (PW) {
-                const unsigned self = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                      ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)self, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-                *reinterpret_cast<unsigned *>(hbuf + nxt + wr_pk + (2 * q) * 16) = __builtin_amdgcn_perm(nb, self, pk_sel);
             } else {
                 *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
                 *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
@@ -301,268 +263,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     };
     if constexpr (ABL & 64) tprev = __builtin_amdgcn_s_memtime();
 
-    // ---- SPL: one step with split synchronisation (see the template comment) ------------------------
-    static_assert(!(SPL != 0 && ABL != 0), "ablation builds use the barrier schedule");
-    const unsigned flag_off = lds_offset(hflag);
-    bool spl_dead = false;       // a wait timed out: stop waiting (results are then wrong, the tests fail loudly)
-    // wait until the four waves of `half` (0: waves 0..3, 1: waves 4..7) have published `target` steps
-    auto wait_half = [&](int half, unsigned target) {
-        if (spl_dead) return;
-        int spins = 0;
-        while (true) {
-            uintx4 f;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag_off + 16u * half) : "memory");
-            const unsigned lo = min(min(f[0], f[1]), min(f[2], f[3]));
-            if ((int)(__builtin_amdgcn_readfirstlane(lo) - target) >= 0) break;
-            if (++spins > kSplSpinLimit) { spl_dead = true; break; }
-        }
-    };
-    const unsigned img_off = lds_offset(hbuf) + (unsigned)rd_off;
-    // wait for `half` and read its two A fragments (k-steps 2*half, 2*half + 1 of the image at byte `cur`)
-    auto wait_read = [&](int half, unsigned target, int cur, half8 &x0, half8 &x1) {
-        if constexpr (SPL == 2) {
-            const unsigned a_off = img_off + (unsigned)cur + (unsigned)(2 * half) * kHKStride;
-            int spins = 0;
-            while (true) {
-                uintx4 f;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(f), "=&v"(x0), "=&v"(x1)
-                             : "v"(flag_off + 16u * half), "v"(a_off), "n"(kHKStride)
-                             : "memory");
-                const unsigned lo = min(min(f[0], f[1]), min(f[2], f[3]));
-                if (spl_dead || (int)(__builtin_amdgcn_readfirstlane(lo) - target) >= 0) break;
-                if (++spins > kSplSpinLimit / 4) { spl_dead = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } else {
-            wait_half(half, target);
-            x0 = *reinterpret_cast<const half8 *>(hbuf + cur + (2 * half) * kHKStride + rd_off);
-            x1 = *reinterpret_cast<const half8 *>(hbuf + cur + (2 * half + 1) * kHKStride + rd_off);
-        }
-    };
-    auto spl_step = [&](int step, int p, int cur, int nxt) {
-        const unsigned done = (unsigned)(step - s0);     // steps every wave has to have published before this one
-        auto rows = [&](const floatx4 &v, int q) {
-            if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
-        };
-        float hn[NQ];
-        if constexpr (CELL == 0 && ZL) {
-            floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
-            if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }
-            half8 a0, a1, a2, a3;
-            wait_read(0, done, cur, a0, a1);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) { ar = mfma16(a0, wf[0][0][sp], ar); az = mfma16(a0, wf[0][1][sp], az); }
-            anh = mfma16(a0, wf[0][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a0, wf[0][2][1], anl);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) { ar = mfma16(a1, wf[1][0][sp], ar); az = mfma16(a1, wf[1][1][sp], az); }
-            anh = mfma16(a1, wf[1][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a1, wf[1][2][1], anl);
-            refill((p + PF - 1) % PF, (step + PF) < s_end);
-            wait_read(1, done, cur, a2, a3);
-            // second half: r and n tiles first ...
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) ar = mfma16(a2, wf[2][0][sp], ar);
-            anh = mfma16(a2, wf[2][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a2, wf[2][2][1], anl);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) ar = mfma16(a3, wf[3][0][sp], ar);
-            anh = mfma16(a3, wf[3][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a3, wf[3][2][1], anl);
-            __builtin_amdgcn_sched_barrier(0);
-            // ... then the z tile, with sigmoid(r), tanh and (h_prev - n) under its MFMAs
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) az = mfma16(a2, wf[2][1][sp], az);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) az = mfma16(a3, wf[3][1][sp], az);
-            float nn[NQ], dd[NQ], gzv[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float gr, gnv;
-                if constexpr (XIN) { gr = 0.f; gzv[q] = 0.f; gnv = rows(gin, q); }
-                else { gr = gq[p][q * NG]; gzv[q] = gq[p][q * NG + 1]; gnv = gq[p][q * NG + 2]; }
-                const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
-                float tn;
-                if constexpr (HP) tn = anh[q] + bhn;
-                else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                const float an = __builtin_fmaf(rr, tn, gnv);
-                const float e = __builtin_amdgcn_exp2f(an * c_tanh);
-                nn[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                dd[q] = hprev[q] - nn[q];
-            }
-#pragma unroll
-            for (int i = 0; i < 2 * NS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4 * NQ + 1, 0);       // VALU
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float tz = XIN ? rows(az, q) : (gzv[q] + rows(az, q));
-                const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
-                const float h = __builtin_fmaf(zz, dd[q], nn[q]);
-                hprev[q] = h;
-                hn[q] = h;
-            }
-        } else if constexpr (CELL == 0) {
-            floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
-            if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
-            // ---- first half of K: units of waves 0..3
-            half8 a0, a1, a2, a3;
-            wait_read(0, done, cur, a0, a1);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ar = mfma16(a0, wf[0][0][sp], ar);
-                az = mfma16(a0, wf[0][1][sp], az);
-            }
-            anh = mfma16(a0, wf[0][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a0, wf[0][2][1], anl);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ar = mfma16(a1, wf[1][0][sp], ar);
-                az = mfma16(a1, wf[1][1][sp], az);
-            }
-            anh = mfma16(a1, wf[1][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a1, wf[1][2][1], anl);
-            // refill the ring slot consumed in the PREVIOUS step; unconditional, in ring order
-            refill((p + PF - 1) % PF, (step + PF) < s_end);
-            // ---- second half of K: units of waves 4..7 (their gate math ran under the MFMAs above)
-            wait_read(1, done, cur, a2, a3);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ar = mfma16(a2, wf[2][0][sp], ar);
-                az = mfma16(a2, wf[2][1][sp], az);
-            }
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ar = mfma16(a3, wf[3][0][sp], ar);
-                az = mfma16(a3, wf[3][1][sp], az);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            anh = mfma16(a2, wf[2][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a2, wf[2][2][1], anl);
-            anh = mfma16(a3, wf[3][2][0], anh);
-            if constexpr (!HP) anl = mfma16(a3, wf[3][2][1], anl);
-            float rr[NQ], zz[NQ], gnv[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float gr, gz;
-                if constexpr (XIN) { gr = 0.f; gz = 0.f; gnv[q] = rows(gin, q); }
-                else { gr = gq[p][q * NG]; gz = gq[p][q * NG + 1]; gnv[q] = gq[p][q * NG + 2]; }
-                const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
-                const float tz = XIN ? rows(az, q) : (gz + rows(az, q));
-                rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
-                zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
-            }
-#pragma unroll
-            for (int i = 0; i < 2 * NS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float tn;
-                if constexpr (HP) tn = anh[q] + bhn;
-                else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
-                const float e = __builtin_amdgcn_exp2f(an * c_tanh);
-                const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
-                hprev[q] = h;
-                hn[q] = h;
-            }
-        } else {
-            // ---- LSTM cell: all four gate tiles over the first half of K, then i, f, g over the second
-            // half and the o tile last with the cell update under its MFMAs
-            floatx4 ai = floatx4{0.f, 0.f, 0.f, 0.f}, af = ai, ag = ai, ao = ai;
-            half8 a0, a1, a2, a3;
-            wait_read(0, done, cur, a0, a1);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ai = mfma16(a0, wf[0][0][sp], ai);
-                af = mfma16(a0, wf[0][1][sp], af);
-                ag = mfma16(a0, wf[0][2][sp], ag);
-                ao = mfma16(a0, wf[0][3][sp], ao);
-            }
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ai = mfma16(a1, wf[1][0][sp], ai);
-                af = mfma16(a1, wf[1][1][sp], af);
-                ag = mfma16(a1, wf[1][2][sp], ag);
-                ao = mfma16(a1, wf[1][3][sp], ao);
-            }
-            refill((p + PF - 1) % PF, (step + PF) < s_end);
-            wait_read(1, done, cur, a2, a3);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ai = mfma16(a2, wf[2][0][sp], ai);
-                af = mfma16(a2, wf[2][1][sp], af);
-                ag = mfma16(a2, wf[2][2][sp], ag);
-            }
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                ai = mfma16(a3, wf[3][0][sp], ai);
-                af = mfma16(a3, wf[3][1][sp], af);
-                ag = mfma16(a3, wf[3][2][sp], ag);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) ao = mfma16(a2, wf[2][3][sp], ao);
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp) ao = mfma16(a3, wf[3][3][sp], ao);
-            float tc[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float ti = gq[p][q * NG + 0] + rows(ai, q);
-                const float tf = gq[p][q * NG + 1] + rows(af, q);
-                const float tg = gq[p][q * NG + 2] + rows(ag, q);
-                const float iv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ti * c_sig));
-                const float fv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tf * c_sig));
-                const float gv = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tg * c_tanh)), 1.0f);
-                const float cv = __builtin_fmaf(fv, hprev[q], iv * gv);
-                hprev[q] = cv;
-                tc[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cv * 2.88539008177792681472f)), 1.0f);
-            }
-#pragma unroll
-            for (int i = 0; i < 2 * NS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float to = gq[p][q * NG + 3] + rows(ao, q);
-                const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(to * c_sig));
-                hn[q] = ov * tc[q];
-            }
-        }
-        // ---- publish h: the fp16 image for the next step first (that is what the other waves wait for),
-        // then the flag, then the HBM store of the layer output
-        publish(hn, nxt);
-        asm volatile("ds_write_b32 %0, %1" ::"v"(flag_off + 4u * (unsigned)w8), "v"(done + 1u) : "memory");
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (step < s_end) op[q][0] = hn[q];
-            op[q] += ostride;
-        }
-        if constexpr (XIN) {
-            // layer-0 input projection of the NEXT step: independent of h, issued here so that it runs on
-            // the matrix pipe while this wave waits for the other waves' flags
-            const half8 xn = xq[(p + 1) % PF];
-            const floatx4 zero = floatx4{0.f, 0.f, 0.f, 0.f};
-            xar = mfma16(xn, wx[0][0], zero);
-            xaz = mfma16(xn, wx[1][0], zero);
-            xgn = mfma16(xn, wx[2][0], zero);
-            if constexpr (!HP) {
-                xar = mfma16(xn, wx[0][1], xar);
-                xaz = mfma16(xn, wx[1][1], xaz);
-                xgn = mfma16(xn, wx[2][1], xgn);
-            }
-        }
-    };
 
     for (int step0 = s0; step0 < s_end; step0 += PF) {
 #pragma unroll
@@ -574,10 +274,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                 stamp(0);   // refill issue + loop overhead
 
                 half8 a[4];
-                if constexpr (SPL != 0) {
-                    spl_step(step, p, cur, nxt);
-                    continue;
-                }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
@@ -588,57 +284,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                     if constexpr (HP) return v[q]; else return v[2 * q] + v[2 * q + 1];
                 };
                 float hn[NQ];
-                if constexpr (CELL == 0 && ZL) {
-                    static_assert(!(ZL && ABL), "ablation builds use the n-last order");
-                    floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
-                    if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
-                    // phase 1: r and n tiles
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                        for (int sp = 0; sp < NS; ++sp) ar = mfma16(a[ks], wf[ks][0][sp], ar);
-                        anh = mfma16(a[ks], wf[ks][2][0], anh);
-                        if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
-                    }
-                    refill((p + PF - 1) % PF, (step + PF) < s_end);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // phase 2: z tile; sigmoid(r), tanh and (h_prev - n) are interleaved with its MFMAs
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int sp = 0; sp < NS; ++sp) az = mfma16(a[ks], wf[ks][1][sp], az);
-                    float nn[NQ], dd[NQ], gzv[NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        float gr, gnv;
-                        if constexpr (XIN) { gr = 0.f; gzv[q] = 0.f; gnv = rows(gin, q); }
-                        else { gr = gq[p][q * NG]; gzv[q] = gq[p][q * NG + 1]; gnv = gq[p][q * NG + 2]; }
-                        const float tr = XIN ? rows(ar, q) : (gr + rows(ar, q));
-                        const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
-                        float tn;
-                        if constexpr (HP) tn = anh[q] + bhn;
-                        else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
-                        const float an = __builtin_fmaf(rr, tn, gnv);
-                        const float e = __builtin_amdgcn_exp2f(an * c_tanh);
-                        nn[q] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-                        dd[q] = hprev[q] - nn[q];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4 * NS; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2 * NQ + 1, 0);   // VALU
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const float tz = XIN ? rows(az, q) : (gzv[q] + rows(az, q));
-                        const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
-                        const float h = __builtin_fmaf(zz, dd[q], nn[q]);
-                        hprev[q] = h;
-                        hn[q] = h;
-                        if (step < s_end) op[q][0] = h;
-                    }
-                } else if constexpr (CELL == 0) {
+                if constexpr (CELL == 0) {
                     floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar, gin = ar;
                     if constexpr (XIN) { ar = xar; az = xaz; gin = xgn; }   // projected one step ahead
                     if constexpr (ABL & 1) {

@@ -76,7 +76,6 @@ struct mdk_rl {
     hipStream_t side = nullptr;               // next layer's projection under this layer's recurrence
     std::vector<hipEvent_t> ov_ev;
     int opt_overlap = 1;
-    int opt_split_sync = 0;   // lstm_size 128 recurrence: per-wave flags + half-K waits (rec_mfma.hpp SPL)
     std::vector<LstmLayer> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
     // workspace
@@ -403,8 +402,6 @@ extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
         m->opt_tile_windows = value;
     } else if (!strcmp(key, "wide_async")) {
         m->opt_async = value ? 1 : 0;
-    } else if (!strcmp(key, "split_sync")) {
-        m->opt_split_sync = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value ? 1 : 0;
     } else if (!strcmp(key, "wide_write_through")) {
@@ -715,15 +712,13 @@ static int rl_forward_dev_inner(mdk_rl *m, const unsigned char *x_dev, int B, in
         if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM
-#define MDK_REC_S(NQV, HPF, SPLV)                                                                  \
-    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, false, HPF, 1, 0, SPLV>), rgrid, dim3(512), 0, s, m->gi, \
+#define MDK_REC(NQV, HPF)                                                                          \
+    hipLaunchKernelGGL((k_rec_mfma<MDK_PF, NQV, false, HPF, 1>), rgrid, dim3(512), 0, s, m->gi,     \
                        (const half8 *)nullptr, (const half8 *)nullptr, Ld.whh_frag, Ld.bias, outp, n_tiles, T, D, \
                        Ld.inv_rec, Ld.reverse_mask, (const int *)nullptr, 0, 0, T)
-#define MDK_REC(NQV, HPF) do { if (m->opt_split_sync) MDK_REC_S(NQV, HPF, 2); else MDK_REC_S(NQV, HPF, 0); } while (0)
         if (hp) { if (nq == 1) MDK_REC(1, true); else if (nq == 2) MDK_REC(2, true); else MDK_REC(4, true); }
         else { if (nq == 1) MDK_REC(1, false); else MDK_REC(2, false); }
 #undef MDK_REC
-#undef MDK_REC_S
         in = outp;
         din = D;
     }

@@ -8,13 +8,15 @@ Reference flow (medaka/prediction.py:113-168):
 `install()` wraps `ModelStoreTGZ.load_model`: the reference builds and loads its own model
 exactly as before; if the result is a `GRUModel` the engine supports AND the target device is
 a HIP device, an engine-backed `medaka_amd.models.GRUModel` with the same `state_dict()` is
-returned instead.  `medaka inference --cpu`, read-level models and unsupported shapes keep
+returned instead.  `medaka inference --cpu` and unsupported shapes keep
 the reference implementation -- the engine itself never runs on the CPU.  `LatentSpaceLSTM`
 models with cnn_size = 128 and lstm_size = 128, or lstm_size = 384 uni-directional (the bundled
 `rl_lstm384`), are accelerated too.
 
 Opt in with `MEDAKA_AMD=1` in the environment of `medaka inference` or by
-calling `install()` before `medaka.prediction.predict(args)`.
+calling `install()` before `medaka.prediction.predict(args)`.  `MEDAKA_AMD=strict` additionally turns every
+"keeping the reference model" decision on a HIP device into an `EngineRequired` error -- the launcher
+(`medaka_amd.launch`) uses it, so a multi-GPU job can never run PyTorch-ROCm's stock RNN path unnoticed.
 """
 import functools
 import logging
@@ -40,57 +42,92 @@ def _rl_supported(model):
             and getattr(model, "num_classes", 5) == 5 and getattr(model, "pooler_type", "mean") == "mean")
 
 
-def _engine_or_reference(new, reference_model):
-    """Build the C-ABI engine now; anything it rejects keeps the reference model (docstring promise)."""
+class EngineRequired(RuntimeError):
+    """Strict mode (`MEDAKA_AMD=strict`): the reference model would have been kept."""
+
+
+def strict_from_env():
+    """`MEDAKA_AMD=strict` (what `medaka_amd.launch` sets for its children): a model the engine cannot take
+    is an error, not a quiet return to PyTorch-ROCm's stock RNN path."""
+    return os.environ.get("MEDAKA_AMD", "0").strip().lower() == "strict"
+
+
+def _keep_reference(model, why, strict):
+    """The one place a reference model is handed back for a HIP device: loud in strict mode."""
+    name = type(model).__name__
+    if strict:
+        raise EngineRequired(f"medaka_amd (strict): {name} stays on the reference implementation: {why}")
+    logger.warning("medaka_amd: %s (%s), keeping the reference model", name, why)
+    return model
+
+
+def _finalise(new, dev, reference_model, strict):
+    """Move the engine-backed model to the device and build the C-ABI engine NOW, so that anything the
+    engine rejects shows up at load time and not at the first batch."""
     from medaka_amd import lib as _lib
+    new = new.to(dev).eval()
     try:
         new.engine()
     except (_lib.EngineError, ValueError, KeyError) as e:
-        logger.warning("medaka_amd: engine rejected %s (%s), keeping the reference model",
-                       type(reference_model).__name__, e)
-        return reference_model
+        return _keep_reference(reference_model, f"engine rejected it: {e}", strict)
+    logger.info("medaka_amd: %s -> %s.%s on %s", type(reference_model).__name__, type(new).__module__,
+                type(new).__name__, dev)
     return new
 
 
-def convert(model, device=None):
-    """Return an engine-backed equivalent of a reference model, or the model itself."""
+def _copy_state(new, model):
+    """Every tensor of the reference model's state_dict, by name, strictly: the mirrors in
+    medaka_amd.models declare the same parameters AND buffers as the reference classes (the unused
+    `read_level_conv.expansion_layer` and the batch-norm `num_batches_tracked` counters included)."""
+    new.load_state_dict(model.state_dict(), strict=True)
+    new.normalise = getattr(model, "normalise", True)
+    if getattr(model, "half_precision", False):
+        new.half()
+    return new
+
+
+def convert(model, device=None, strict=None):
+    """Return an engine-backed equivalent of a reference model (reference flow: the object
+    `ModelStoreTGZ.load_model` returns, datastore.py:135-157, built by `model_from_dict`, models.py:392-400).
+
+    Non-HIP devices (`medaka inference --cpu`) keep the reference model.  On a HIP device a model the engine
+    does not cover keeps the reference implementation with a warning -- or, with `strict` (default: the
+    `MEDAKA_AMD=strict` environment), raises `EngineRequired`."""
     import torch
     from medaka_amd import models as amd_models
 
+    strict = strict_from_env() if strict is None else bool(strict)
     name = type(model).__name__
     dev = torch.device(device) if device is not None else model.device()
     if dev.type != "cuda":
         return model
     if isinstance(model, (amd_models.GRUModel, amd_models.MajorityVoteModel, amd_models.LatentSpaceLSTM)):
         return model
-    if name == "GRUModel" and _gru_supported(model):
+    if name == "GRUModel":
+        if not _gru_supported(model):
+            return _keep_reference(model, "outside the engine's envelope (gru_size 128, 1-4 layers, <= 16 features)", strict)
         kwargs = model.to_dict()["kwargs"]
         kwargs.pop("time_steps", None)
         kwargs.pop("classify_activation", None)
-        new = amd_models.GRUModel(**kwargs)
-        new.load_state_dict(model.state_dict(), strict=True)      # same parameter names as the reference
-        new.normalise = getattr(model, "normalise", True)
-        if getattr(model, "half_precision", False):
-            new.half()
-        return _engine_or_reference(new.to(dev).eval(), model)
-    if name == "LatentSpaceLSTM" and _rl_supported(model):
+        try:
+            new = _copy_state(amd_models.GRUModel(**kwargs), model)
+        except (RuntimeError, TypeError, ValueError) as e:
+            return _keep_reference(model, f"state_dict mismatch: {e}", strict)
+        return _finalise(new, dev, model, strict)
+    if name == "LatentSpaceLSTM":
+        if not _rl_supported(model):
+            return _keep_reference(model, "outside the engine's envelope (cnn_size 128, kernel_sizes [1, 17], mean pooling, "
+                                          "lstm_size 128 or uni-directional 384)", strict)
         kwargs = model.to_dict()["kwargs"]
         kwargs.pop("time_steps", None)
-        new = amd_models.LatentSpaceLSTM(**kwargs)
-        state = {k: v for k, v in model.state_dict().items()
-                 if "num_batches_tracked" not in k and "read_level_conv.expansion_layer" not in k}
-        missing = new.load_state_dict(state, strict=False)
-        if missing.unexpected_keys or any("num_batches_tracked" not in k for k in missing.missing_keys):
-            logger.warning("medaka_amd: state_dict mismatch (%s), keeping the reference model", missing)
-            return model
-        new.normalise = getattr(model, "normalise", True)
-        if getattr(model, "half_precision", False):
-            new.half()
-        return _engine_or_reference(new.to(dev).eval(), model)
+        try:
+            new = _copy_state(amd_models.LatentSpaceLSTM(**kwargs), model)
+        except (RuntimeError, TypeError, ValueError) as e:
+            return _keep_reference(model, f"state_dict mismatch: {e}", strict)
+        return _finalise(new, dev, model, strict)
     if name == "MajorityVoteModel":
         return amd_models.MajorityVoteModel().to(dev).eval()
-    logger.info("medaka_amd: %s is not accelerated, keeping the reference model", name)
-    return model
+    return _keep_reference(model, "no engine for this architecture", strict)
 
 
 def install():
@@ -119,7 +156,7 @@ def uninstall():
 
 def install_from_env():
     """`MEDAKA_AMD=1` -> install(); used by the sitecustomize hook of INTEGRATION.md."""
-    if os.environ.get("MEDAKA_AMD", "0") not in ("", "0"):
+    if os.environ.get("MEDAKA_AMD", "0").strip().lower() not in ("", "0", "off", "false"):
         install()
         return True
     return False

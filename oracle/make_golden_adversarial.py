@@ -99,16 +99,23 @@ def gru_part():
     np.savez_compressed(os.path.join(GOLD, "gru_adversarial.npz"), **out)
 
 
-def rl_half_part():
+def rl_half_part(only=None):
+    """`only`: recompute just these cases and merge them into the committed JSON (round 3 added "wide_nd")."""
     arch, models, te = ref_shim.reference_modules()
     rep = {}
+    path = os.path.join(GOLD, "rl_half_emulation.json")
+    if only and os.path.exists(path):
+        rep = json.load(open(path))
     cases = [("bi", dict(), f"rl_weights_bi.npz"), ("uni", dict(bidirectional=False), "rl_weights_uni.npz"),
              ("bi_dwells", dict(use_dwells=True), "rl_weights_bi_dwells.npz"),
              ("wide", dict(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=False), None),
+             ("wide_nd", dict(lstm_size=384, cnn_size=128, use_dwells=False, bidirectional=False), None),
              ("trained", dict(), "rl_weights_trained.npz")]
     for name, kw, wfile in cases:
+        if only and name not in only:
+            continue
         if wfile is None:
-            state = rl_oracle.synth_rl_state(seed=21, **kw)
+            state = rl_oracle.synth_rl_state(seed=22 if name == "wide_nd" else 21, **kw)
         elif not os.path.exists(os.path.join(GOLD, wfile)):
             continue
         else:
@@ -129,7 +136,7 @@ def rl_half_part():
                      "argmax_agreement": float((y16.argmax(-1) == y32.argmax(-1)).mean()),
                      "input": "rl_oracle.synth_reads(4, 400, 20, seed=77)"}
         print("half emulation", name, rep[name])
-    json.dump(rep, open(os.path.join(GOLD, "rl_half_emulation.json"), "w"), indent=1)
+    json.dump(rep, open(path, "w"), indent=1)
 
 
 def rl_trained_part():
@@ -174,3 +181,5 @@ if __name__ == "__main__":
         rl_trained_part()
     if "rl_half" in which:
         rl_half_part()
+    if "rl_half_wide_nd" in which:
+        rl_half_part(only=("wide_nd",))

@@ -18,6 +18,10 @@ WIDE_SEED = 21
 # name -> (windows, positions, padded depth, input seed): "two_groups" = one full + one ragged
 # 8-window group; "many_groups" = 17 groups > 16 clusters, so clusters loop over groups
 WIDE_CASES = {"two_groups": (11, 150, 7, 31), "many_groups": (130, 24, 3, 32)}
+# rl_lstm384 WITHOUT dwells: 4 of the 8 bundled read-level models (reference options.py:175-182) take the
+# `use_dwells=False` branch of latent_space_lstm.py:176-190 (4 features per read, 7 conv input channels)
+WIDE_ND_SEED = 22
+WIDE_ND_CASES = {"two_groups": (11, 150, 7, 41), "many_groups": (130, 24, 3, 42), "long": (3, 1100, 5, 43)}
 
 
 def main():
@@ -61,5 +65,25 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "rl_wide_cases.npz"), **wide)
 
 
+def main_wide_no_dwells():
+    arch, models, te = ref_shim.reference_modules()
+    kw = dict(lstm_size=384, cnn_size=128, use_dwells=False, bidirectional=False)
+    state = rl_oracle.synth_rl_state(seed=WIDE_ND_SEED, **kw)
+    m = arch.LatentSpaceLSTM(**kw).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    out = {}
+    for name, (B, P, D, seed) in WIDE_ND_CASES.items():
+        x = rl_oracle.synth_reads(B, P, D, use_dwells=False, seed=seed)
+        y = m.predict_on_batch(te.Batch(read_level_features=torch.from_numpy(x))).numpy()
+        out[f"{name}/x"] = x
+        out[f"{name}/y"] = y
+        print("wide no-dwells", name, y.shape,
+              float(np.abs(rl_oracle.rl_forward(x, state, use_dwells=False, bidirectional=False) - y).max()))
+    np.savez_compressed(os.path.join(GOLD, "rl_wide_nd_cases.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--wide-no-dwells" in sys.argv:       # added in round 3; leaves the earlier fixtures untouched
+        main_wide_no_dwells()
+    else:
+        main()

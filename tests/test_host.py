@@ -220,6 +220,125 @@ def test_integration_hook_keeps_reference_model_on_cpu(tmp_path):
     assert ds.ModelStoreTGZ.load_model.__name__ == "load_model"
 
 
+# ---- the model swap (integration.convert): every family, against the real classes and their stand-ins ----
+import json  # noqa: E402
+
+import ref_standins  # noqa: E402
+
+
+def _ref_keys():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_state_keys.json")))
+
+
+@pytest.mark.parametrize("name", sorted(ref_standins.CONFIGS))
+def test_standins_have_the_reference_surface(name):
+    """tests/ref_standins.py (what the GPU box swaps) == the unmodified reference classes: same `to_dict()`, same
+    state_dict keys / order / shapes / dtypes (golden from oracle/make_golden_keys.py; live when the tree is here)."""
+    cls, kw = ref_standins.CONFIGS[name]
+    want = _ref_keys()[name]
+    assert ref_standins.describe(cls(**kw)) == want
+    if ref_shim.available():
+        arch, _, _ = ref_shim.reference_modules()
+        live = getattr(arch, cls.__name__)(**kw)
+        assert ref_standins.describe(live) == want
+
+
+def _randomise(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                v.copy_(torch.rand(v.shape, generator=g) * 0.4 + (0.5 if k.endswith("running_var") else -0.2))
+            else:
+                v.fill_(7)          # num_batches_tracked
+
+
+def _no_device(monkeypatch):
+    """No HIP device here: skip ONLY the move to the device and the engine build of `_finalise`."""
+    from medaka_amd import integration
+    monkeypatch.setattr(integration, "_finalise", lambda new, dev, ref, strict: new.eval())
+    return integration
+
+
+@pytest.mark.parametrize("source", ["reference", "standin"])
+@pytest.mark.parametrize("name", sorted(ref_standins.CONFIGS))
+def test_convert_swaps_every_model_family(name, source, monkeypatch):
+    """`convert()` must hand back an ENGINE-backed class for GRUModel, LatentSpaceLSTM() and
+    both rl_lstm384 variants built by the unmodified reference (datastore.py:135-157 -> models.py:392-400), with
+    every tensor carried over -- `read_level_conv.expansion_layer.*` and `num_batches_tracked` included."""
+    if source == "reference":
+        if not ref_shim.available():
+            pytest.skip("reference tree not present")
+        arch, _, _ = ref_shim.reference_modules()
+        cls, kw = getattr(arch, ref_standins.CONFIGS[name][0].__name__), ref_standins.CONFIGS[name][1]
+    else:
+        cls, kw = ref_standins.CONFIGS[name]
+    integration = _no_device(monkeypatch)
+    ref = cls(**kw).eval()
+    _randomise(ref, 5)
+    new = integration.convert(ref, device="cuda", strict=True)
+    assert type(new).__module__ == "medaka_amd.models" and type(new).__name__ == type(ref).__name__
+    assert hasattr(new, "engine")
+    rs, ns = ref.state_dict(), new.state_dict()
+    assert list(rs) == list(ns)
+    for k in rs:
+        assert torch.equal(rs[k], ns[k]), k
+    assert new.to_dict() == ref.to_dict()
+    assert not new.training and new.normalise is True and new.half_precision is False
+    # half precision set before the swap survives it (prediction.py:164-168 calls half() after the load, but a
+    # caller may convert an already-halved model)
+    halved = cls(**kw).eval()
+    halved.half()                     # (the reference's half() returns None, models.py:298-301)
+    new_h = integration.convert(halved, device="cuda", strict=True)
+    assert new_h.half_precision is True
+    # `--cpu`: the reference model itself comes back, also in strict mode
+    assert integration.convert(ref, device="cpu", strict=True) is ref
+    assert integration.convert(new, device="cuda") is new          # idempotent
+
+
+def test_convert_strict_mode_raises_instead_of_falling_back(monkeypatch, caplog):
+    """`MEDAKA_AMD=strict` (set by medaka_amd.launch): anything that would keep PyTorch-ROCm's stock path on a
+    HIP device is an error; the default mode logs a warning and returns the reference model."""
+    integration = _no_device(monkeypatch)
+    outside = [ref_standins.GRUModel(gru_size=64), ref_standins.LatentSpaceLSTM(lstm_size=384, bidirectional=True),
+               ref_standins.LatentSpaceLSTM(cnn_size=64), ref_standins.LatentSpaceLSTM(kernel_sizes=[1, 9])]
+
+    class SomethingElse(ref_standins._Base):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+    outside.append(SomethingElse())
+    for m in outside:
+        with caplog.at_level("WARNING", logger="medaka_amd"):
+            caplog.clear()
+            assert integration.convert(m, device="cuda", strict=False) is m
+            assert "keeping the reference model" in caplog.text
+        with pytest.raises(integration.EngineRequired):
+            integration.convert(m, device="cuda", strict=True)
+    monkeypatch.setenv("MEDAKA_AMD", "strict")
+    assert integration.strict_from_env()
+    with pytest.raises(integration.EngineRequired):
+        integration.convert(outside[0], device="cuda")             # strict=None -> environment
+    monkeypatch.setenv("MEDAKA_AMD", "1")
+    assert not integration.strict_from_env()
+    assert integration.convert(outside[0], device="cuda") is outside[0]
+
+
+def test_convert_engine_rejection_is_loud_in_strict_mode(monkeypatch):
+    """The real `_finalise`: an engine that cannot be built (no device here, or a rejected shape) keeps the
+    reference model by default and raises in strict mode."""
+    from medaka_amd import integration, lib as _lib, models as amd_models
+
+    def boom(self):
+        raise _lib.EngineError("mdk_gru_create: bad argument: simulated")
+    monkeypatch.setattr(amd_models.GRUModel, "engine", boom)
+    monkeypatch.setattr(torch.nn.Module, "to", lambda self, *a, **k: self)
+    ref = ref_standins.GRUModel()
+    assert integration.convert(ref, device="cuda", strict=False) is ref
+    with pytest.raises(integration.EngineRequired, match="simulated"):
+        integration.convert(ref, device="cuda", strict=True)
+
+
 def _build_c_host(tmp_path):
     import subprocess
     from medaka_amd import build as _build

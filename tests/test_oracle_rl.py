@@ -46,3 +46,19 @@ def test_rl_oracle_matches_reference_goldens_lstm384(name):
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 1e-5
     assert (out.argmax(-1) == ref.argmax(-1)).mean() >= 0.999
+
+
+@pytest.mark.parametrize("name", ["two_groups", "many_groups", "long"])
+def test_rl_oracle_matches_reference_goldens_lstm384_no_dwells(name):
+    """The `use_dwells=False` flavour of rl_lstm384 (4 of the 8 bundled read-level models, reference
+    options.py:175-182; branch latent_space_lstm.py:186-190): outputs from the unmodified reference."""
+    from oracle.make_golden_rl import WIDE_ND_SEED
+    cases = np.load(os.path.join(GOLD, "rl_wide_nd_cases.npz"))
+    state = rl_oracle.synth_rl_state(seed=WIDE_ND_SEED, lstm_size=384, cnn_size=128, use_dwells=False, bidirectional=False)
+    x = cases[f"{name}/x"]
+    assert x.shape[-1] == 4
+    out = rl_oracle.rl_forward(x, state, use_dwells=False, bidirectional=False)
+    ref = cases[f"{name}/y"]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-5
+    assert (out.argmax(-1) == ref.argmax(-1)).mean() >= 0.999
