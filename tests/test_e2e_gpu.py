@@ -176,3 +176,45 @@ def test_production_loop_shape_bitwise_and_gil(gold, model):
     t.join()
     print(f"ticker: {free_rate:,.0f}/s free, {busy_rate:,.0f}/s during forwards")
     assert busy_rate > 0.5 * free_rate
+
+
+def test_writer_thread_holds_rows_of_earlier_batches(model):
+    """The `DataStore` pattern (reference datastore.py:196, 263-299, 323-329): `run_prediction` hands every
+    row of `predict_on_batch`'s output -- a VIEW of the returned tensor -- to a one-thread executor and goes
+    on to the next batch at once (prediction.py:44-52), so rows of several earlier batches are still queued
+    while new forwards run.  `predict_on_batch` returns page-locked tensors that torch's host allocator
+    recycles (medaka_amd/models.py: _host_output): a block may only be reused once every view is gone.
+    Here the writer is held back until six batches have been produced; every held row must then still carry
+    exactly the bits of its own batch, and live outputs never share storage."""
+    from concurrent.futures import ThreadPoolExecutor
+    from medaka_amd import synth
+    n_batches, B, T = 6, 24, 2304
+    batches = [Batch(counts_matrix=torch.from_numpy(synth.counts_windows(B, T, depth=50, seed=900 + b)))
+               for b in range(n_batches)]
+    gate, written, futures = threading.Event(), {}, []
+    executor = ThreadPoolExecutor(1)                 # DataStore.write_executor
+
+    def write_dataset(location, data):               # DataStore._write_dataset: reads the tensor when its turn comes
+        gate.wait()
+        written[location] = data.numpy().copy()
+    storages = []
+    for b, batch in enumerate(batches):
+        class_probs = model.predict_on_batch(batch)
+        storages.append(class_probs.untyped_storage().data_ptr())
+        for i, prob in enumerate(class_probs):       # prediction.py:47
+            futures.append(executor.submit(write_dataset, (b, i), prob))
+        del class_probs, prob
+    assert len(set(storages)) == n_batches           # six outputs alive in the writer queue: six distinct blocks
+    gate.set()
+    for f in futures:
+        f.result()
+    executor.shutdown()
+    del futures
+    for b, batch in enumerate(batches):
+        again = model.predict_on_batch(batch).numpy()
+        for i in range(B):
+            assert np.array_equal(written[(b, i)], again[i]), (b, i)
+    # with the views gone the allocator hands the blocks out again: no growth in steady state
+    later = {model.predict_on_batch(batches[0]).untyped_storage().data_ptr() for _ in range(4)}
+    print(f"held blocks {len(set(storages))}, blocks seen after release {len(later)}")
+    assert later & set(storages) or len(later) <= 2
