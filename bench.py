@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
+    ap.add_argument("--loop-batches", type=int, default=14,
+                    help="batches of the fed loop (threaded loader -> collate -> predict_on_batch -> writer; 0 = skip)")
     return ap.parse_args()
 
 
@@ -147,6 +149,135 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
               "argmax_identical": bool((probs_sample[:n].argmax(-1) == ref.argmax(-1)).all()),
               "tolerance": 1e-4, "columns_checked": int(n * T)}
     return base, parity
+
+
+class LoopSample:
+    """What the prediction loop reads of a `medaka.common.Sample` (common.py:60-80): a name and the features view."""
+    __slots__ = ("name", "features", "labels")
+
+    def __init__(self, name, features):
+        self.name, self.features, self.labels = name, features, None
+
+
+def reference_collate(samples):
+    """The expression of the reference's `Batch.collate` for counts matrices (torch_ext.py:147-148)."""
+    import torch
+    from medaka_amd.torch_ext import Batch
+    return Batch(counts_matrix=torch.stack([torch.from_numpy(s.features) for s in samples]).float())
+
+
+def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sample_workers=2):
+    """The engine inside the thread structure of the reference's inference loop (prediction.py:36-60, 225-370):
+    `sample_workers` loader threads put Samples (views of a region's feature array, as `Sample.chunks` makes them)
+    on a bounded queue, ONE Batcher thread groups `batch_size` of them and runs `collate`, the main thread calls
+    `model.predict_on_batch` and hands every row of the result to a one-thread writer (DataStore.write_executor,
+    datastore.py:196) that copies it out -- the minimum an HDF5 write does.  Queues block instead of spinning
+    (the reference polls with get_nowait).  Returns per-batch timings; the first `warm` batches are not counted."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    total = n_batches * batch_size
+    samples_q, batches_q = queue.Queue(maxsize=cache * batch_size), queue.Queue(maxsize=cache)
+    DONE = object()
+
+    def region_worker(k):
+        for i in range(k, total, sample_workers):
+            samples_q.put((i, LoopSample(f"w{i}", windows[i % len(windows)])))
+        samples_q.put(DONE)
+    collate_ms = []
+
+    def batch_worker():
+        pending, stops, nxt = {}, 0, 0
+        data = []
+        while stops < sample_workers or pending:
+            if stops < sample_workers:
+                item = samples_q.get()
+                if item is DONE:
+                    stops += 1
+                else:
+                    pending[item[0]] = item[1]
+            while nxt in pending:                      # samples in region order, as one loader per region yields them
+                data.append(pending.pop(nxt))
+                nxt += 1
+                if len(data) == batch_size:
+                    t0 = time.perf_counter()
+                    batch = collate(data)
+                    collate_ms.append(1e3 * (time.perf_counter() - t0))
+                    batches_q.put((data, batch))
+                    data = []
+        batches_q.put(DONE)
+    threads = [threading.Thread(target=region_worker, args=(k,), daemon=True) for k in range(sample_workers)]
+    threads.append(threading.Thread(target=batch_worker, daemon=True))
+    for t in threads:
+        t.start()
+    writer = ThreadPoolExecutor(1)
+    sink = np.empty(windows[0].shape[0] * 5, dtype=np.float32)
+    touched = [0]
+
+    def write_row(prob):
+        np.copyto(sink, prob.numpy().reshape(-1))
+        touched[0] += 1
+    predict_ms, wait_ms, futures, t_start, done = [], [], [], None, 0
+    while True:
+        t0 = time.perf_counter()
+        item = batches_q.get()
+        if item is DONE:
+            break
+        data, batch = item
+        t1 = time.perf_counter()
+        class_probs = model.predict_on_batch(batch)
+        t2 = time.perf_counter()
+        for sample, prob in zip(data, class_probs):
+            futures.append(writer.submit(write_row, prob))
+        del class_probs, batch, item
+        done += 1
+        wait_ms.append(1e3 * (t1 - t0)); predict_ms.append(1e3 * (t2 - t1))
+        if done == warm:
+            for f in futures:
+                f.result()
+            futures = []
+            t_start = time.perf_counter()
+    for f in futures:
+        f.result()
+    elapsed = time.perf_counter() - t_start
+    writer.shutdown()
+    for t in threads:
+        t.join()
+    assert touched[0] == total
+    timed = n_batches - warm
+    cols = timed * batch_size * windows[0].shape[0]
+    return {"value": cols / elapsed, "unit": "pileup columns/s", "ms_per_batch": 1e3 * elapsed / timed,
+            "timed_batches": timed, "warmup_batches": warm,
+            "collate_ms_median": statistics.median(collate_ms[warm:]),
+            "predict_ms_median": statistics.median(predict_ms[warm:]),
+            "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:])}
+
+
+def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
+    """`fed_loop` with the reference's collate and with the engine's (medaka_amd.torch_ext.stack_counts)."""
+    import numpy as np
+    from medaka_amd import synth, torch_ext
+    step = T - 1000                                  # chunk_len 10000, chunk_ovlp 1000 (medaka.py:266-272)
+    n_win = 64
+    base = synth.counts_windows(8, step, depth=depth, seed=seed).reshape(-1, 10)
+    region = np.concatenate([base] * (-(-((n_win - 1) * step + T) // base.shape[0])))
+    windows = [region[i * step:i * step + T] for i in range(n_win)]    # overlapping views, like Sample.chunks
+    out = {"what": "sample workers -> Batcher thread (collate) -> model.predict_on_batch -> one-thread writer that copies "
+                   "every row out; thread structure of reference prediction.py:36-60, 225-370",
+           "batch_windows": B, "chunk_len": T}
+    fast = lambda data: torch_ext.Batch.collate(data)
+    for name, fn in (("reference_collate", reference_collate), ("engine_collate", fast)):
+        fed_loop(model, windows, B, 3, fn, warm=1)                     # allocator warm-up (page-locked blocks)
+        out[name] = fed_loop(model, windows, B, n_batches, fn)
+        log(f"fed loop, {name}: {out[name]['value'] / 1e6:.1f} M columns/s, collate {out[name]['collate_ms_median']:.2f} ms, "
+            f"predict {out[name]['predict_ms_median']:.2f} ms per batch")
+    out["value"] = out["engine_collate"]["value"]
+    out["engine_collate"]["threads"] = torch_ext.COLLATE_THREADS
+    if host_to_host_rate:
+        out["frac_of_host_to_host"] = out["value"] / host_to_host_rate
+        out["reference_collate"]["frac_of_host_to_host"] = out["reference_collate"]["value"] / host_to_host_rate
+    return out
 
 
 RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
@@ -414,6 +545,9 @@ def main():
                 os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), x_host, probs, args.cpu_budget)
             if result["cpu_baseline"]["value"]:
                 result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        if args.loop_batches > 2 and ranks.world == 1:
+            result["fed_loop"] = loop_report(model, B, T, args.depth, 4321, args.loop_batches,
+                                             result["host_to_host"]["value"])
         # the same with the PCIe diet (SURVEY 8f f2 + f3): uint16 counts + uint32 depth in (24 B/column),
         # argmax class + its probability out (5 B/column)
         cnt = np.minimum(np.rint(x_host * 60.0), 65535).astype(np.uint16)

@@ -39,7 +39,7 @@ def build(force=False, verbose=False, extra_flags=()):
     # its own temporary and renames it into place atomically, so nobody ever loads a partial file
     tmp = f"{LIB}.tmp.{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-ffp-contract=off", "-pthread",
            "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + list(extra_flags)
     if verbose:
         print(" ".join(cmd), flush=True)

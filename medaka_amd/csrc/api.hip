@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/medaka_amd.h"
@@ -1011,6 +1012,30 @@ extern "C" int mdk_host_alloc(size_t bytes, void **ptr) {
 }
 extern "C" int mdk_host_free(void *ptr) {
     if (ptr) HIP_TRY(hipHostFree(ptr));
+    return MDK_OK;
+}
+// Batch assembly (reference Batch.collate -> torch.stack, torch_ext.py:147-148) with a few host threads.
+extern "C" int mdk_gather_rows(void *dst, const void *const *rows, int n_rows, size_t row_bytes, int n_threads) {
+    if (n_rows < 0) return fail(MDK_ERR_ARG, "negative n_rows");
+    if (n_rows == 0 || row_bytes == 0) return MDK_OK;
+    if (!dst || !rows) return fail(MDK_ERR_ARG, "null buffer");
+    for (int i = 0; i < n_rows; ++i)
+        if (!rows[i]) return fail(MDK_ERR_ARG, "row %d is null", i);
+    n_threads = std::max(1, std::min(std::min(n_threads, 64), n_rows));
+    auto work = [=](int k) {
+        const int lo = (int)((long)n_rows * k / n_threads), hi = (int)((long)n_rows * (k + 1) / n_threads);
+        for (int i = lo; i < hi; ++i) memcpy(static_cast<char *>(dst) + (size_t)i * row_bytes, rows[i], row_bytes);
+    };
+    if (n_threads == 1) { work(0); return MDK_OK; }
+    std::vector<std::thread> pool;
+    try {
+        for (int k = 1; k < n_threads; ++k) pool.emplace_back(work, k);
+    } catch (...) {            // thread creation failed: finish what was not handed out on this thread
+        const int started = (int)pool.size();
+        for (int k = started + 1; k < n_threads; ++k) work(k);
+    }
+    work(0);
+    for (auto &t : pool) t.join();
     return MDK_OK;
 }
 extern "C" int mdk_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {

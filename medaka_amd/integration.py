@@ -130,28 +130,52 @@ def convert(model, device=None, strict=None):
     return _keep_reference(model, "no engine for this architecture", strict)
 
 
-def install():
-    """Patch `medaka.datastore.ModelStoreTGZ.load_model` (idempotent)."""
+def _fast_collate(orig):
+    """`Batch.collate` of the reference (torch_ext.py:110-173) with its counts-matrix branch assembled by
+    `medaka_amd.torch_ext.stack_counts`; every other case (read-level features, labels, odd dtypes) is the
+    reference's own code.  Same class, same fields, same values."""
+    from medaka_amd.torch_ext import stack_counts
+
+    def collate(cls, samples, counts_matrix=False):
+        first = samples[0] if len(samples) else None
+        if first is not None and getattr(first.features, "ndim", 0) == 2 and getattr(first, "labels", None) is None:
+            return cls(counts_matrix=stack_counts([s.features for s in samples]))
+        return orig(cls, samples, counts_matrix)
+    return collate
+
+
+def install(collate=None):
+    """Patch `medaka.datastore.ModelStoreTGZ.load_model` (the model swap) and -- unless `collate` is False or
+    `MEDAKA_AMD_COLLATE=0` -- `medaka.torch_ext.Batch.collate` (batch assembly in the Batcher thread,
+    prediction.py:356-370).  Idempotent."""
     import medaka.datastore as ds
 
-    if "load_model" in _ORIG:
-        return
-    orig = ds.ModelStoreTGZ.load_model
+    if "load_model" not in _ORIG:
+        orig = ds.ModelStoreTGZ.load_model
 
-    @functools.wraps(orig)
-    def load_model(self, time_steps=None, device=None, *args, **kwargs):
-        model = orig(self, time_steps=time_steps, device=device, *args, **kwargs)
-        self.model = convert(model, device)
-        return self.model
+        @functools.wraps(orig)
+        def load_model(self, time_steps=None, device=None, *args, **kwargs):
+            model = orig(self, time_steps=time_steps, device=device, *args, **kwargs)
+            self.model = convert(model, device)
+            return self.model
 
-    _ORIG["load_model"] = orig
-    ds.ModelStoreTGZ.load_model = load_model
+        _ORIG["load_model"] = orig
+        ds.ModelStoreTGZ.load_model = load_model
+    if collate is None:
+        collate = os.environ.get("MEDAKA_AMD_COLLATE", "1").strip().lower() not in ("0", "off", "false")
+    if collate and "collate" not in _ORIG:
+        import medaka.torch_ext as rte
+        _ORIG["collate"] = rte.Batch.__dict__["collate"]           # the classmethod object itself
+        rte.Batch.collate = classmethod(_fast_collate(_ORIG["collate"].__func__))
 
 
 def uninstall():
     if "load_model" in _ORIG:
         import medaka.datastore as ds
         ds.ModelStoreTGZ.load_model = _ORIG.pop("load_model")
+    if "collate" in _ORIG:
+        import medaka.torch_ext as rte
+        rte.Batch.collate = _ORIG.pop("collate")
 
 
 def install_from_env():

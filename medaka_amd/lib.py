@@ -77,6 +77,7 @@ ABI = {
     "mdk_dev_free": (_i, [_i, _vp]),
     "mdk_host_alloc": (_i, [_sz, ctypes.POINTER(_vp)]),
     "mdk_host_free": (_i, [_vp]),
+    "mdk_gather_rows": (_i, [_vp, ctypes.POINTER(_vp), _i, _sz, _i]),
     "mdk_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
     "mdk_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
     "mdk_device_synchronize": (_i, [_i]),

@@ -220,6 +220,65 @@ def test_integration_hook_keeps_reference_model_on_cpu(tmp_path):
     assert ds.ModelStoreTGZ.load_model.__name__ == "load_model"
 
 
+def test_batch_assembly_matches_the_reference_expression():
+    """`stack_counts` (mdk_gather_rows on a few host threads) == `torch.stack([...]).float()` of reference
+    torch_ext.py:147-148, for overlapping row views as `Sample.chunks` makes them; odd inputs take the reference
+    expression itself."""
+    from medaka_amd import torch_ext as te
+    rng = np.random.default_rng(3)
+    big = rng.random((5000, 10), dtype=np.float32)
+    for n, T, step, threads in ((1, 1, 1, 1), (7, 300, 250, 3), (33, 120, 100, 64), (5, 64, 64, 2)):
+        feats = [big[i * step:i * step + T] for i in range(n)]
+        want = torch.stack([torch.from_numpy(f) for f in feats]).float()
+        got = te.stack_counts(feats, threads=threads)
+        assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous()
+        assert torch.equal(got, want)
+    odd = [big[::2][:50], big[::2][50:100]]                       # not C-contiguous
+    assert torch.equal(te.stack_counts(odd), torch.stack([torch.from_numpy(f) for f in odd]).float())
+    f64 = [big[:40].astype(np.float64), big[40:80].astype(np.float64)]
+    out = te.stack_counts(f64)
+    assert out.dtype == torch.float32 and torch.equal(out, torch.stack([torch.from_numpy(f) for f in f64]).float())
+    L = lib.load()
+    assert L.mdk_gather_rows(None, None, 0, 16, 4) == lib.MDK_OK      # empty: nothing to do
+    assert L.mdk_gather_rows(None, None, 3, 16, 4) == lib.MDK_ERR_ARG
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_install_patches_the_reference_collate_compatibly():
+    """`integration.install()` replaces the counts-matrix branch of the reference's own `Batch.collate`
+    (what the Batcher thread calls, prediction.py:356-370); every result equals the unpatched one."""
+    ref_shim.install()
+    import medaka.common as mc
+    import medaka.torch_ext as rte
+    from medaka_amd import integration
+    rng = np.random.default_rng(0)
+    big = rng.random((3000, 10), dtype=np.float32)
+
+    def sample(feat, labels=None):
+        return mc.Sample(ref_name="c", features=feat, labels=labels, ref_seq=None, positions=None,
+                         label_probs=None, depth=None)
+    counts = [sample(big[i * 90:i * 90 + 100]) for i in range(9)]
+    labelled = [sample(big[i * 100:i * 100 + 100], np.arange(100)) for i in range(3)]
+    reads = [sample(rng.integers(0, 5, (6, d, 4)).astype(np.uint8)) for d in (3, 5)]
+    before = [rte.Batch.collate(x) for x in (counts, labelled, reads)]
+    integration.install(collate=True)
+    try:
+        assert rte.Batch.collate.__func__ is not integration._ORIG["collate"].__func__
+        after = [rte.Batch.collate(x) for x in (counts, labelled, reads)]
+    finally:
+        integration.uninstall()
+    for a, b in zip(before, after):
+        assert type(a) is type(b) is rte.Batch
+        for field in ("counts_matrix", "read_level_features", "labels", "majority_vote_probs"):
+            va, vb = getattr(a, field), getattr(b, field)
+            assert (va is None) == (vb is None), field
+            if va is not None:
+                assert va.dtype == vb.dtype and torch.equal(va, vb), field
+    assert rte.Batch.collate.__func__.__qualname__ == "Batch.collate"      # restored
+    with pytest.raises(IndexError):
+        rte.Batch.collate([])                                             # the reference's own error, unpatched
+
+
 # ---- the model swap (integration.convert): every family, against the real classes and their stand-ins ----
 import json  # noqa: E402
 
