@@ -389,6 +389,8 @@ def main():
     from medaka_amd import dist, models, synth
 
     log('start')
+    if args.shared_gpu:      # K processes on ONE GPU (medaka_amd.launch --procs-per-gpu K): every engine takes 1/K of the CUs
+        os.environ.setdefault("MEDAKA_AMD_PROCS_PER_GPU", os.environ.get("WORLD_SIZE", "1"))
     ranks = dist.Ranks(backend="gloo" if args.shared_gpu else None)
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: launch with "

@@ -57,11 +57,12 @@ typedef struct {
 
 /* Per-kernel device time of the last timed forward, milliseconds (hipEvent based). */
 typedef struct {
-    float h2d_ms;
+    float h2d_ms;         /* always 0 since the host copies stream under the recurrences (mdk_gru_forward): there is no
+                             separate copy span to report; kept for ABI stability -- time the call itself instead */
     float gi_ms[4];       /* input projection per layer */
     float rec_ms[4];      /* recurrence per layer (both directions) -- the dominant kernel */
     float head_ms;        /* Linear + softmax */
-    float d2h_ms;
+    float d2h_ms;         /* always 0, as h2d_ms */
     float total_ms;       /* first kernel start -> last kernel end (device-resident region) */
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
@@ -115,6 +116,8 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
  *   "deferred_store"       = 1 | 0                  recurrence: h_t leaves for HBM from inside step t+1 (default 1)
+ *   "gpu_share"            = 1 .. 8                 processes sharing this GPU (medaka_amd.launch --procs-per-gpu):
+ *                                                   work-group sizes are chosen so that all of them fit the chip
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;

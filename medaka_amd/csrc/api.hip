@@ -84,6 +84,7 @@ struct mdk_gru {
     size_t gi2_rows = 0;
     int opt_overlap = 1;
     int opt_deferred_store = 1;              // recurrence: HBM store of h_t from inside step t+1 (rec_mfma.hpp DS)
+    int opt_gpu_share = 1;                   // processes sharing this GPU (launch.py --procs-per-gpu): divides the CU budgets below
     int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
     // timing
     bool timing = false;
@@ -310,6 +311,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_deferred_store = value ? 1 : 0;
     } else if (!strcmp(key, "stream_host")) {
         m->opt_stream_host = value ? 1 : 0;
+    } else if (!strcmp(key, "gpu_share")) {
+        if (value < 1 || value > 8) return fail(MDK_ERR_ARG, "gpu_share must be 1..8");
+        m->opt_gpu_share = value;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -469,7 +473,11 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     int nq = 1;
     // (profiles/run_tile_sweep.sh: at 256 work-groups of 4 windows the 8-window variant + overlap is
     // already 3 % ahead, at 200 it is 3 % behind)
-    while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > 232) nq *= 2;
+    // one work-group owns a CU (8 waves x <= 256 VGPRs), so a call wants all its work-groups resident at once; with
+    // `gpu_share` processes on the GPU each takes its share of the 256 CUs (work-groups of different processes
+    // do run side by side, profiles/r3_procs_per_gpu.txt), otherwise the surplus queues behind the others
+    const int cu_budget = 232 / m->opt_gpu_share;
+    while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > cu_budget) nq *= 2;
     if (m->opt_tile_windows == 4) nq = 1;
     if (m->opt_tile_windows == 8) nq = 2;
     if (m->opt_tile_windows == 16 && hp) nq = 4;
@@ -514,7 +522,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const bool ablated = (abl != 0 && !hp && nq <= 2);
     const bool can_chunk = D == 2 && !ablated && T >= 2048 && T % (2 * kGemmSteps) == 0;
     const bool overlap = m->opt_overlap && can_chunk && L >= 2 &&
-                         (n_wg * D <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
+                         (n_wg * D * m->opt_gpu_share <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
     const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
     const bool stream_out = io_out && can_chunk && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence

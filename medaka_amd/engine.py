@@ -58,26 +58,25 @@ class DeviceBuffer:
 
 class PinnedArray:
     """Page-locked host buffer from the C ABI (`mdk_host_alloc`) with a numpy view: reusable input /
-    output of `GruEngine.forward_host(x, out=...)` for hosts without torch's pinned allocator."""
+    output of `GruEngine.forward_host(x, out=...)` for hosts without torch's pinned allocator.
+
+    The memory belongs to the ctypes block `.array` is built on and is released by a finalizer of that
+    block, i.e. only after the last numpy view of it is gone: views may outlive the PinnedArray object."""
 
     def __init__(self, shape, dtype=np.float32):
-        self.ptr = ctypes.c_void_p()
+        import weakref
+        ptr = ctypes.c_void_p()
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        _lib.check(_lib.load().mdk_host_alloc(max(nbytes, 1), ctypes.byref(self.ptr)), "mdk_host_alloc")
-        buf = (ctypes.c_char * max(nbytes, 1)).from_address(self.ptr.value)
-        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        _lib.check(_lib.load().mdk_host_alloc(max(nbytes, 1), ctypes.byref(ptr)), "mdk_host_alloc")
+        self.ptr = ptr
+        block = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
+        # np.frombuffer keeps `block` alive through the array's base chain; when the last view dies so does the block
+        weakref.finalize(block, _lib.load().mdk_host_free, ctypes.c_void_p(ptr.value))
+        self.array = np.frombuffer(block, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def free(self):
-        if self.ptr:
-            self.array = None
-            _lib.load().mdk_host_free(self.ptr)
-            self.ptr = ctypes.c_void_p()
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+        """Drop this object's own view (the memory follows once no other view is left)."""
+        self.array = None
 
 
 class GruEngine:
@@ -155,6 +154,9 @@ class GruEngine:
         (argmax class uint8, its probability float32): normalisation (features.py:907-911) and
         argmax decode (labels.py:1061-1065) run on the device."""
         counts = np.asarray(counts)
+        if counts.dtype.kind not in "ui":
+            raise ValueError(f"pileup counts must be integers (got {counts.dtype}): normalised features go through "
+                             "forward_host / predict_on_batch")
         if counts.dtype != np.uint16:
             # the reference's counts are size_t (src/medaka_counts.c); the device path carries uint16
             if counts.size and (counts.max() > 65535 or counts.min() < 0):

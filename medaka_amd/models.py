@@ -17,6 +17,7 @@ whose parameters are not on a HIP device refuses to predict (use the reference c
 """
 import inspect
 import logging
+import os
 import warnings
 
 import numpy as np
@@ -107,6 +108,14 @@ class CountsMatrixModel(TorchModel):
             raise ValueError(f"{type(fenc)} is not a valid feature encoder for {clsname}.")
 
 
+def gpu_share():
+    """Processes sharing this process's GPU: `MEDAKA_AMD_PROCS_PER_GPU`, set by `medaka_amd.launch --procs-per-gpu`."""
+    try:
+        return max(1, min(8, int(os.environ.get("MEDAKA_AMD_PROCS_PER_GPU", "1"))))
+    except ValueError:
+        return 1
+
+
 def _hip_device_index(dev):
     if dev.type != "cuda":
         raise RuntimeError(
@@ -159,6 +168,7 @@ class GRUModel(CountsMatrixModel):
                 n_layers=self.n_layers, bidirectional=self.bidirectional, num_classes=5,
                 normalise=bool(self.normalise), device=dev_index)
             self._engine_key = key
+            self._engine.set_option("gpu_share", gpu_share())
         self._engine.set_precision(self.half_precision)
         self._engine.set_variant(self.kernel_variant if self.kernel_variant is not None
                                  else int(self.exact_kernels))
@@ -331,6 +341,11 @@ class LatentSpaceLSTM(ReadLevelFeaturesModel):
 
     def engine(self):
         dev_index = _hip_device_index(self.device())
+        if self.lstm_size == 384 and gpu_share() > 1:
+            raise _lib.EngineError(
+                "LatentSpaceLSTM(lstm_size=384): the cluster recurrence keeps one work-group on each of 192 CUs for "
+                f"a whole layer and cannot share its GPU (MEDAKA_AMD_PROCS_PER_GPU={gpu_share()}); run one process "
+                "per GPU for the rl_lstm384 models")
         key = (dev_index, tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters()),
                tuple((b.data_ptr(), b._version) for b in self.buffers()))
         if self._engine is None or self._engine_key != key:

@@ -12,7 +12,12 @@ fixed_size=False, common.py:711-736).  `shard_regions` hands out THOSE pieces --
 `bam_chunk` long, so the per-GPU process does not cut it again -- which makes the set of regions, hence
 of pileups, windows and samples, identical to a single-process run: the stitched consensus of the
 joined HDFs is the same by construction (tests/test_e2e_gpu.py checks it against the reference's
-own FASTQ).  Pieces are assigned longest-first to the least loaded shard (LPT), ties by input order.
+own FASTQ).  One exception is handled explicitly: a trailing piece SHORTER than `chunk_len` would, as a
+region of its own, take the child's `region.size < chunk_len` branch (prediction.py:97-98: un-chunked
+remainder pass) whereas a single process keeps it in the batched pass (it is only the *contig* that is tested
+there).  Such a tail therefore travels together with its predecessor as ONE region [prev.start, end): the
+child re-cuts it on the same grid into the same two pieces and the tail stays in the batched pass.
+Pieces are assigned longest-first to the least loaded shard (LPT), ties by input order.
 """
 from collections import namedtuple
 
@@ -35,16 +40,29 @@ def split_region(region, chunk, overlap):
             for s in range(region.start, region.end, chunk - overlap)]
 
 
-def shard_regions(contigs, n_shards, bam_chunk=1_000_000, chunk_ovlp=1000):
+def shardable_pieces(region, bam_chunk, chunk_ovlp, chunk_len):
+    """`split_region`, with a trailing piece shorter than `chunk_len` joined to its predecessor (module
+    docstring): every returned region is cut by the child exactly as a single process cuts the contig."""
+    pieces = split_region(region, bam_chunk, chunk_ovlp)
+    if len(pieces) > 1 and pieces[-1].end - pieces[-1].start < chunk_len:
+        prev, tail = pieces[-2], pieces[-1]
+        if tail.end - prev.start > bam_chunk:          # the child will re-cut [prev.start, end) into prev + tail
+            pieces[-2:] = [Region(region.ref_name, prev.start, tail.end)]
+        # else: the tail lies inside its predecessor (fewer than chunk_ovlp bases were left); it is redundant for
+        # the consensus and is kept as the reference's grid has it
+    return pieces
+
+
+def shard_regions(contigs, n_shards, bam_chunk=1_000_000, chunk_ovlp=1000, chunk_len=10000):
     """contigs: iterable of (name, length) or Region.  Returns list[n_shards] of list[Region], every
-    region one piece of the reference's own bam_chunk grid.  Deterministic."""
+    region one piece of the reference's own bam_chunk grid (or a last piece + its short tail).  Deterministic."""
     if n_shards < 1:
         raise ValueError("n_shards must be >= 1")
     pieces = []
     for c in contigs:
         r = c if isinstance(c, Region) else Region(c[0], 0, int(c[1]))
         if r.end > r.start:      # (a single process cuts its regions itself)
-            pieces.extend(split_region(r, bam_chunk, chunk_ovlp) if n_shards > 1 else [r])
+            pieces.extend(shardable_pieces(r, bam_chunk, chunk_ovlp, chunk_len) if n_shards > 1 else [r])
     order = sorted(range(len(pieces)), key=lambda i: (-(pieces[i].end - pieces[i].start), i))
     shards = [[] for _ in range(n_shards)]
     load = [0] * n_shards

@@ -204,7 +204,16 @@ def test_streamed_host_path_agrees_bitwise(gold):
     e.set_option("stream_host", 0)
     assert np.array_equal(e.forward_host(big), a)
     e.close()
+    # a view may outlive its PinnedArray: the page-locked block is released with the last view
+    import gc
+    row = pin_p.array[3]
     pin_x.free(); pin_p.free()
+    del pin_x, pin_p
+    gc.collect()
+    assert np.array_equal(row, plain[3])
+    del row
+    with pytest.raises(ValueError, match="integers"):
+        engine.GruEngine.forward_counts_host(None, np.ones((1, 2, 10), np.float32), np.ones((1, 2), np.uint32))
     _check(plain, oracle.c_gru_forward(x, weight_set(gold, "trained")), what="streamed host path", strict_argmax=True)
 
 
