@@ -388,6 +388,7 @@ def main():
     graft.build()
     from medaka_amd import dist, models, synth
 
+    torch.set_num_threads(usable_cores())       # host-side torch ops (the reference's collate): the cores we really have
     log('start')
     if args.shared_gpu:      # K processes on ONE GPU (medaka_amd.launch --procs-per-gpu K): every engine takes 1/K of the CUs
         os.environ.setdefault("MEDAKA_AMD_PROCS_PER_GPU", os.environ.get("WORLD_SIZE", "1"))

@@ -22,7 +22,24 @@ def _gpu_available():
         return False
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    CPUs and grants 16: 256 torch threads on a 16-core quota made one CPU-oracle pass take > 20 minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def pytest_collection_modifyitems(config, items):
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:            # no test may hang a GPU box: the slowest one takes ~40 s
+            if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(420))
     if _gpu_available():
         return
     skip = pytest.mark.skip(reason="no HIP device visible")
@@ -36,6 +53,8 @@ def _built():
     """The engine must be built before any test: no silent fallback."""
     import __graft_entry__ as g
     g.build()
+    import torch
+    torch.set_num_threads(usable_cores())      # CPU oracles: never more threads than the cgroup grants
 
 
 @pytest.fixture(scope="session")
