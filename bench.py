@@ -166,13 +166,16 @@ def reference_collate(samples):
     return Batch(counts_matrix=torch.stack([torch.from_numpy(s.features) for s in samples]).float())
 
 
-def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sample_workers=2):
+def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sample_workers=2, per_sample_submit=False):
     """The engine inside the thread structure of the reference's inference loop (prediction.py:36-60, 225-370):
     `sample_workers` loader threads put Samples (views of a region's feature array, as `Sample.chunks` makes them)
     on a bounded queue, ONE Batcher thread groups `batch_size` of them and runs `collate`, the main thread calls
     `model.predict_on_batch` and hands every row of the result to a one-thread writer (DataStore.write_executor,
-    datastore.py:196) that copies it out -- the minimum an HDF5 write does.  Queues block instead of spinning
-    (the reference polls with get_nowait).  Returns per-batch timings; the first `warm` batches are not counted."""
+    datastore.py:196) that copies it out -- the minimum an HDF5 write does.  By default the main thread hands a
+    batch's rows to the writer with ONE submit; `per_sample_submit` does it the reference's way, one executor submit
+    per sample from the main thread (the reference makes one per sample FIELD, datastore.py:283-300), which costs the
+    main thread ~45 us each under GIL contention.  Queues block instead of spinning (the reference polls with
+    get_nowait).  Returns per-batch timings; the first `warm` batches are not counted."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -218,7 +221,11 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
     def write_row(prob):
         np.copyto(sink, prob.numpy().reshape(-1))
         touched[0] += 1
-    predict_ms, wait_ms, futures, t_start, done = [], [], [], None, 0
+
+    def write_rows(class_probs):
+        for prob in class_probs:
+            write_row(prob)
+    predict_ms, wait_ms, hand_ms, futures, t_start, done = [], [], [], [], None, 0
     while True:
         t0 = time.perf_counter()
         item = batches_q.get()
@@ -228,11 +235,15 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
         t1 = time.perf_counter()
         class_probs = model.predict_on_batch(batch)
         t2 = time.perf_counter()
-        for sample, prob in zip(data, class_probs):
-            futures.append(writer.submit(write_row, prob))
+        if per_sample_submit:
+            for sample, prob in zip(data, class_probs):
+                futures.append(writer.submit(write_row, prob))
+            del prob
+        else:
+            futures.append(writer.submit(write_rows, class_probs))
         del class_probs, batch, item
         done += 1
-        wait_ms.append(1e3 * (t1 - t0)); predict_ms.append(1e3 * (t2 - t1))
+        wait_ms.append(1e3 * (t1 - t0)); predict_ms.append(1e3 * (t2 - t1)); hand_ms.append(1e3 * (time.perf_counter() - t2))
         if done == warm:
             for f in futures:
                 f.result()
@@ -251,7 +262,9 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
             "timed_batches": timed, "warmup_batches": warm,
             "collate_ms_median": statistics.median(collate_ms[warm:]),
             "predict_ms_median": statistics.median(predict_ms[warm:]),
-            "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:])}
+            "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:]),
+            "main_thread_hand_to_writer_ms_median": statistics.median(hand_ms[warm:]),
+            "writer_submits_per_batch": batch_size if per_sample_submit else 1}
 
 
 def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
@@ -272,6 +285,8 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
         out[name] = fed_loop(model, windows, B, n_batches, fn)
         log(f"fed loop, {name}: {out[name]['value'] / 1e6:.1f} M columns/s, collate {out[name]['collate_ms_median']:.2f} ms, "
             f"predict {out[name]['predict_ms_median']:.2f} ms per batch")
+    out["engine_collate_per_sample_submit"] = fed_loop(model, windows, B, n_batches, fast, per_sample_submit=True)
+    log(f"fed loop, engine collate, one writer submit per sample: {out['engine_collate_per_sample_submit']['value'] / 1e6:.1f} M columns/s")
     out["value"] = out["engine_collate"]["value"]
     out["engine_collate"]["threads"] = torch_ext.COLLATE_THREADS
     if host_to_host_rate:

@@ -120,22 +120,28 @@ def rl_half_part(only=None):
             continue
         else:
             state = dict(np.load(os.path.join(GOLD, wfile)))
-        x = rl_oracle.synth_reads(4, 400, 20, use_dwells=kw.get("use_dwells", False), seed=77)
+        inputs = [(name, rl_oracle.synth_reads(4, 400, 20, use_dwells=kw.get("use_dwells", False), seed=77),
+                   "rl_oracle.synth_reads(4, 400, 20, seed=77)")]
+        if name.startswith("wide") and only:
+            # the shapes tests/test_parity_gpu.py::test_wide_read_level_half_precision runs (few reads per window: less
+            # averaging in the pool, larger fp16 deviations than the 20-read case above)
+            inputs += [(f"{name}/{B}x{P}x{D}", rl_oracle.synth_reads(B, P, D, use_dwells=kw.get("use_dwells", False), seed=B + P),
+                        f"rl_oracle.synth_reads({B}, {P}, {D}, seed={B + P})") for B, P, D in ((5, 300, 6), (40, 130, 3), (300, 20, 2))]
         m32 = arch.LatentSpaceLSTM(**kw).eval()
         m32.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
-        with torch.inference_mode():
-            y32 = m32.forward(torch.from_numpy(x)).float().numpy()
         m16 = arch.LatentSpaceLSTM(**kw).eval()
         m16.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
         m16.half()                     # (the reference half() returns None: models.py:298-301)
-        # the reference's GPU path: fp16 weights + autocast (models.py:303-313); on the CPU the same pair
-        with torch.inference_mode(), torch.autocast("cpu", dtype=torch.float16):
-            y16 = m16.forward(torch.from_numpy(x)).float().numpy()
-        d = np.abs(y16 - y32)
-        rep[name] = {"max_abs_dp": float(d.max()), "mean_abs_dp": float(d.mean()),
-                     "argmax_agreement": float((y16.argmax(-1) == y32.argmax(-1)).mean()),
-                     "input": "rl_oracle.synth_reads(4, 400, 20, seed=77)"}
-        print("half emulation", name, rep[name])
+        for key, x, what in inputs:
+            with torch.inference_mode():
+                y32 = m32.forward(torch.from_numpy(x)).float().numpy()
+            # the reference's GPU path: fp16 weights + autocast (models.py:303-313); on the CPU the same pair
+            with torch.inference_mode(), torch.autocast("cpu", dtype=torch.float16):
+                y16 = m16.forward(torch.from_numpy(x)).float().numpy()
+            d = np.abs(y16 - y32)
+            rep[key] = {"max_abs_dp": float(d.max()), "mean_abs_dp": float(d.mean()),
+                        "argmax_agreement": float((y16.argmax(-1) == y32.argmax(-1)).mean()), "input": what}
+            print("half emulation", key, rep[key])
     json.dump(rep, open(path, "w"), indent=1)
 
 
@@ -183,3 +189,5 @@ if __name__ == "__main__":
         rl_half_part()
     if "rl_half_wide_nd" in which:
         rl_half_part(only=("wide_nd",))
+    if "rl_half_wide_shapes" in which:       # round 3: per-shape anchors of both rl_lstm384 flavours
+        rl_half_part(only=("wide", "wide_nd"))

@@ -8,7 +8,7 @@ R=$PWD; OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp
 has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 if has tests; then
-  timeout 1500 python -m pytest tests -m gpu -x -q -s -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
+  timeout 700 python -m pytest tests -m gpu -x -q -s --durations=8 -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
   echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu.log"; grep "^\[swap\]" "$OUT/pytest_gpu.log"
 fi
 if has bench; then
@@ -19,7 +19,7 @@ fi
 if has procs; then
   # K inference processes sharing ONE MI355X (medaka_amd.launch --procs-per-gpu K): K ranks of bench.py on device 0,
   # started behind a gloo barrier; value = device-resident aggregate, host_to_host = predict_on_batch aggregate
-  for B in 100 200; do
+  for B in 200 100; do
     for K in 1 2 3 4; do
       if [ "$K" = 1 ]; then
         timeout 200 python bench.py --shared-gpu --gpus 1 --batch $B --steps 10 --warmup 3 --cpu-budget 0 --loop-batches 0 \
