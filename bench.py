@@ -298,6 +298,17 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
 RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
 
 
+def rl_traffic(model, B, P, D):
+    """HBM bytes of one k_rl_front launch from the committed PMC summary (profiles/traffic_rl.json: FETCH_SIZE x 2 +
+    WRITE_SIZE, collected by profiles/collect_round3.sh at 100 x 10000 x 50), scaled by the read positions of this run."""
+    path = os.path.join(ROOT, "profiles", "traffic_rl.json")
+    try:
+        t = json.load(open(path))[model]
+        return t["k_rl_front_bytes_per_launch"] * (float(B) * P * D) / t["read_positions"]
+    except Exception:
+        return None
+
+
 def main_rl(args):
     """BASELINE config 4b: the read-level model (reference LatentSpaceLSTM) over uint8 read matrices, one GPU
     per rank, input resident in HBM.  rl384 = the bundled rl_lstm384 architecture (lstm 384, 4 x uni-directional,
@@ -362,7 +373,7 @@ def main_rl(args):
                    "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"},
         "roofline": {"kernel": "k_rl_front (embedding + conv1 + BN + conv17 as an implicit GEMM on MFMA + BN + masked mean over reads)",
                      "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_DENSE_TFLOPS / issue, "unit": "TFLOP/s",
-                     "frac": achieved / (PEAK_F16_DENSE_TFLOPS / issue), "traffic": None,
+                     "frac": achieved / (PEAK_F16_DENSE_TFLOPS / issue), "traffic": rl_traffic(args.model, B, P, D),
                      "avg_launch_ms": statistics.mean(front), "launches_timed": len(front),
                      "algorithmic_flop_per_launch": flop,
                      "note": f"algorithmic = conv2 only, {RL_CONV2_FLOP} FLOP per (window, read, position); peak = fp16 dense "
@@ -372,20 +383,28 @@ def main_rl(args):
     }
     if ranks.rank == 0:
         if args.cpu_budget > 0 and ranks.world == 1:
-            # CPU baseline: the functional PyTorch-CPU restatement of LatentSpaceLSTM.forward on a bounded sample
+            # CPU baseline: the functional PyTorch-CPU restatement of LatentSpaceLSTM.forward (oracle/rl_oracle.py, pinned
+            # to the unmodified reference) on a bounded sample: 8 windows x 2000 positions x D reads, 1 warm-up + median of 3
             from oracle import rl_oracle
-            xs = x_small[:2, :min(P, 400)]
-            torch.set_num_threads(min(usable_cores(), 16))
-            rl_oracle.rl_forward(xs[:1, :50], state, use_dwells=wide, bidirectional=not wide)
-            t0 = time.perf_counter()
-            ref = rl_oracle.rl_forward(xs, state, use_dwells=wide, bidirectional=not wide)
-            dt = time.perf_counter() - t0
+            cores = usable_cores()
+            torch.set_num_threads(cores)
+            xs = x_small[:8, :min(P, 2000)]
+            rl_oracle.rl_forward(xs[:1, :200], state, use_dwells=wide, bidirectional=not wide)
+            times, ref = [], None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ref = rl_oracle.rl_forward(xs, state, use_dwells=wide, bidirectional=not wide)
+                times.append(time.perf_counter() - t0)
+                if sum(times) > args.cpu_budget:
+                    break
+            dt = statistics.median(times)
+            log(f"cpu baseline (read-level oracle): {xs.shape[0] * xs.shape[1] / dt:,.0f} columns/s, {len(times)} passes of {dt:.2f} s on {cores} threads")
             with torch.inference_mode():
                 out = m(torch.from_numpy(np.ascontiguousarray(xs)).to(dev)).cpu().numpy()
             result["cpu_baseline"] = {"value": xs.shape[0] * xs.shape[1] / dt, "unit": "pileup columns/s",
-                                      "cores": min(usable_cores(), 16), "kind": "port",
+                                      "cores": cores, "kind": "port", "passes": len(times), "median_s": dt,
                                       "sample": f"{xs.shape[0]} windows x {xs.shape[1]} positions x {D} reads, "
-                                                "oracle/rl_oracle.py (functional PyTorch-CPU fp32), one pass"}
+                                                f"oracle/rl_oracle.py (functional PyTorch-CPU fp32), median of {len(times)} after a warm-up"}
             result["parity"] = {"max_abs_dp": float(np.abs(out - ref).max()),
                                 "argmax_identical": bool((out.argmax(-1) == ref.argmax(-1)).all()),
                                 "columns_checked": int(xs.shape[0] * xs.shape[1])}
@@ -470,8 +489,10 @@ def main():
         if ranks.rank == 0:
             print(json.dumps({"metric": "pileup columns/sec (consensus bi-GRU inference)", "value": value,
                               "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
-                              "ms_per_step": 1e3 * elapsed / args.steps, "device_only": True,
-                              "rec_ms_per_step": sum(rec_ms) / args.steps}), flush=True)
+                              "ms_per_step": 1e3 * elapsed / args.steps, "device_only": True, "batch_windows": B,
+                              "rec_ms_per_step": sum(rec_ms) / args.steps,
+                              "gi_ms_per_step": statistics.mean(gi_ms[-args.steps:]),
+                              "head_ms_per_step": statistics.mean(head_ms[-args.steps:])}), flush=True)
         ranks.close()
         return
     # host tensor in -> host tensor out (what run_prediction's loop sees), every rank at once

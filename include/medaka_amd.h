@@ -184,7 +184,9 @@ int mdk_rl_forward(mdk_rl *m, const unsigned char *x_host, int B, int P, int D, 
 /* Device-resident variant, enqueued on `stream`.  lstm_size 128: asynchronous.  lstm_size 384 (rl_lstm384): the
  * cluster recurrence verifies its cross-CU exchange, so by default the call SYNCHRONISES `stream`, and after a
  * time-out (a late cluster member: the path wants 192 CUs of the GPU to itself) re-runs once on the plain
- * schedule before failing with MDK_ERR_DEVICE.  Option "wide_async" = 1 makes it asynchronous (no retry);
+ * schedule before failing with MDK_ERR_DEVICE.  A GPU that cannot host the kernel (fewer than 192 free CUs) is
+ * detected by the clusters' placement handshake, bounded at 50 ms of wall clock per try: the error comes back
+ * within ~0.1 s, not after seconds of spinning.  Option "wide_async" = 1 makes it asynchronous (no retry);
  * mdk_rl_check() then reports a time-out of any earlier forward. */
 int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int D, int F, float *probs_dev,
                        void *stream);

@@ -27,6 +27,7 @@ using namespace mdk;
 #define MDK_PF 5   // gi / x prefetch ring depth (effective look-ahead PF-1 steps)
 #endif
 
+
 #include "host_common.hpp"
 
 extern "C" const char *mdk_last_error(void) { return g_mdk_err.c_str(); }
@@ -271,6 +272,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
+
     *out = m;
     return MDK_OK;
 }
@@ -484,15 +486,18 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const int n_wg = (n_win + 4 * nq - 1) / (4 * nq);
     const dim3 rgrid(n_wg, D);
 
-    // projection GEMM of a layer over the 8-step strips [strip0, strip0 + n_strips)
+    // projection GEMM of a layer over the 8-step strips [strip0, strip0 + n_strips): 64-row work-groups, two per CU
+    // (128-row work-groups -- half the L2 traffic for W_ih, one per CU -- are bit-identical and measured 7 % SLOWER at
+    // 1000 x 10000: with one work-group per CU nothing overlaps the staging; profiles/r3_experiments/README.md)
     auto launch_gemm = [&](const LayerDev &Lg, const float *src, float *gi_out, hipStream_t st, int strip0, int n_strips,
                            const int *gcond = nullptr, int gwant = 0) {
         if (n_strips <= 0) return;
+        const int t_end = std::min(T, (strip0 + n_strips) * kGemmSteps);
         const dim3 grid((unsigned)n_strips * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF>), grid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), st, \
                        src, Lg.wih_frag, Lg.bias_gi, gi_out, n_tiles, T, D, Lg.inv_scale_gi, Lg.up_scale_rec, kActScale, strip0, \
-                       gcond, gwant)
+                       gcond, gwant, t_end)
         if (D == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM

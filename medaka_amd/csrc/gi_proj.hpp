@@ -91,8 +91,15 @@ constexpr int kGemmMT = kGemmSteps / 2;        // 16-row MFMA tiles per M-tile
 
 // HP: half-precision mode, one fp16 product instead of the three of the hi/lo split.
 // NG = gate tiles per hidden unit (3 GRU, 4 LSTM): N = NG * 128 columns per direction.
-template <int KSTEPS, bool HP, int NG = 3>   // K = 32 * KSTEPS = D_in * 128
-__global__ __launch_bounds__(512, 4) void k_gi_gemm(
+// MT = 16-row MFMA tiles per work-group: M-tile = 8 windows x 2*MT time steps.
+//   MT = 4 (64 rows, 64 KB of LDS, <= 128 VGPRs, two work-groups per CU): every work-group streams ALL of W_ih
+//          (786 KB of B fragments) from L2 for its 64 rows = 12 KB per row, three times the HBM traffic of the row;
+//          round 2's counters put the kernel at 13.7 TB/s of L2 hits -- bound by L2, not by HBM or the pipe;
+//   MT = 8 (128 rows, 128 KB of LDS, one work-group per CU): 6 KB of L2 per row, bit-identical -- and measured 7 %
+//          SLOWER at 1000 x 10000 (13.1 vs 12.2 ms; round 3, profiles/r3_experiments/README.md): with one work-group
+//          per CU nothing overlaps the staging of the next tile, and L2 was not the limiter after all.  Not instantiated.
+template <int KSTEPS, bool HP, int NG = 3, int MT = kGemmMT>   // K = 32 * KSTEPS = D_in * 128
+__global__ __launch_bounds__(512, MT <= 4 ? 4 : 2) void k_gi_gemm(
     const float *__restrict__ act_in,  // act_t of the previous layer (|x| < 1: GRU outputs)
     const half8 *__restrict__ wfrag,   // [D][8 waves][KSTEPS][NG gates][2 hi/lo][64 lanes]
     const float *__restrict__ bias,    // [D][NG*128]
@@ -100,31 +107,32 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
     int n_tiles, int T, int D, const float *__restrict__ inv_scale_p,
     const float *__restrict__ out_scale_p, float a_scale,   // a_scale: power-of-two operand scale of act_in
     int strip0,                                              // first 8-step strip of this launch
-    const int *__restrict__ cond, int want)                  // run only if (*cond != 0) == want (cond may be null)
+    const int *__restrict__ cond, int want,                  // run only if (*cond != 0) == want (cond may be null)
+    int t_end)                                               // columns >= t_end are neither read nor written
 {
     if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
     constexpr int DIN = KSTEPS / 4;            // directions of the input activations
     constexpr int NP = DIN * 128;              // 8-float pieces per activation block
+    constexpr int STEPS = 2 * MT;              // time steps per work-group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half8 *xs = reinterpret_cast<half8 *>(smem);   // [split 2][mt kGemmMT][KSTEPS][64 lanes]
+    half8 *xs = reinterpret_cast<half8 *>(smem);   // [split 2][mt MT][KSTEPS][64 lanes]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, tile fastest
     const int tile = blockIdx.x % n_tiles;
-    const int strip = strip0 + blockIdx.x / n_tiles;
-    const int t0 = strip * kGemmSteps;
+    const int t0 = strip0 * kGemmSteps + (blockIdx.x / n_tiles) * STEPS;
 
     // ---- stage: 16 blocks x NP pieces; thread-local piece j -> (g, q) fastest (LDS bank spread)
     {
         const float *src0 = act_in + act_block(DIN, tile, T, t0);
-        for (int P = tid; P < kGemmSteps * NP; P += 512) {
+        for (int P = tid; P < STEPS * NP; P += 512) {
             const int tau = P / NP, j = P % NP;
             const int g = j & 3, q = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
             const int piece = chunk * 16 + q * 8 + g * 2 + half;
             float v[8];
-            if (t0 + tau < T) {
+            if (t0 + tau < t_end) {
                 const float *src = src0 + (size_t)tau * (DIN * 1024) + piece * 8;
                 const float4 v0 = *reinterpret_cast<const float4 *>(src);
                 const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
@@ -144,16 +152,16 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
             const int row = 4 * g + 2 * q + (tau & 1), mt = tau >> 1;
             const int k8 = chunk * 2 + half, ks = k8 >> 2;
             const int slot = (k8 & 3) * 16 + row;      // A-fragment lane that consumes it
-            xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = hi;
-            if constexpr (!HP) xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + slot] = lo;
+            xs[((0 * MT + mt) * KSTEPS + ks) * 64 + slot] = hi;
+            if constexpr (!HP) xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot] = lo;
         }
     }
     __syncthreads();
 
     for (int d = 0; d < D; ++d) {
-        floatx4 acc[kGemmMT][NG];
+        floatx4 acc[MT][NG];
 #pragma unroll
-        for (int mt = 0; mt < kGemmMT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NG; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
@@ -167,10 +175,10 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
                 if constexpr (!HP) bl[nt] = wp[(size_t)((ks * NG + nt) * 2 + 1) * 64];
             }
 #pragma unroll
-            for (int mt = 0; mt < kGemmMT; ++mt) {
-                const half8 ah = xs[((0 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
+            for (int mt = 0; mt < MT; ++mt) {
+                const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
                 half8 al;
-                if constexpr (!HP) al = xs[((1 * kGemmMT + mt) * KSTEPS + ks) * 64 + lane];
+                if constexpr (!HP) al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                 for (int nt = 0; nt < NG; ++nt) {
                     acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
@@ -190,12 +198,12 @@ __global__ __launch_bounds__(512, 4) void k_gi_gemm(
         for (int nt = 0; nt < NG; ++nt) bv[nt] = bias[(size_t)d * (NG * kH) + nt * kH + 16 * w8 + (lane & 15)] * os;
         float *gblk = gi + gi_block(d, n_tiles, tile, T, t0, NG);
 #pragma unroll
-        for (int mt = 0; mt < kGemmMT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = r >> 1, tt = r & 1;
                 const int t = t0 + 2 * mt + tt;
-                if (t < T) {
+                if (t < t_end) {
                     float *dst = gblk + (size_t)(2 * mt + tt) * gi_block_floats(NG) + gi_in_block(w8, q, 0, lane, NG);
                     typename FloatRun<NG>::vec_t v;
 #pragma unroll

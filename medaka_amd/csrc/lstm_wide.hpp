@@ -44,7 +44,13 @@ constexpr int kWImgBytes = kWKS * kHKStride;   // 13 056 B per A image
 constexpr int kWMaxClusters = 16;              // 2 per XCD
 constexpr int kWGranules = kWWin * kWH;        // per parity buffer
 constexpr size_t kWExchWords = (size_t)kWMaxClusters * 4 * kWGranules + (size_t)kWMaxClusters * 16;   // 2 groups x 2 parities + XCD headers
-constexpr int kWSpinLimit = 1 << 20;           // ~1-2 s of polling before giving up
+constexpr int kWSpinLimit = 1 << 20;           // ~1-2 s of polling before giving up (a member died mid-kernel: never seen)
+// The placement handshake is where a cluster finds out that its 12 members are NOT all resident (fewer than 192
+// CUs free: another tenant holds them).  It is bounded in wall-clock time, not in polls: 50 ms of the constant
+// 100 MHz clock (s_memrealtime) -- launch skew between resident work-groups is microseconds, a foreign kernel may
+// hold CUs for a few milliseconds -- so that a GPU that cannot host the kernel is reported within ~0.1 s (two tries,
+// rl_api.hip) instead of after seconds of spinning.
+constexpr unsigned long long kWHandshakeTicks = 5000000ull;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -118,13 +124,13 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
             __hip_atomic_store(hdr + member, (0x7fffffffull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 64) {
             unsigned long long x = 0;
-            int spins = 0;
+            const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
             bool ok;
             do {
                 if (lane < kWC) x = __hip_atomic_load(hdr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = lane >= kWC || (unsigned int)(x >> 32) == 0x7fffffffu;
                 if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
-            } while (!__all(ok) && ++spins < kWSpinLimit);
+            } while (!__all(ok) && __builtin_amdgcn_s_memrealtime() - t_begin < kWHandshakeTicks);
             const bool same = lane >= kWC || ((unsigned int)x & 0xf) == xcc;
             if (lane == 0) s_same = (__all(ok) && __all(same)) ? 1 : (__all(ok) ? 0 : -1);
         }

@@ -708,7 +708,7 @@ static int rl_forward_dev_inner(mdk_rl *m, const unsigned char *x_dev, int B, in
         const dim3 ggrid(((T + kGemmSteps - 1) / kGemmSteps) * n_tiles);
 #define MDK_GEMM(KS, HPF)                                                                          \
     hipLaunchKernelGGL((k_gi_gemm<KS, HPF, 4>), ggrid, dim3(512), (size_t)2 * kGemmMT * KS * 64 * sizeof(half8), s, \
-                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale, 0, (const int *)nullptr, 0)
+                       in, Ld.wih_frag, Ld.bias, m->gi, n_tiles, T, D, Ld.inv_gi, Ld.up_rec, Ld.a_scale, 0, (const int *)nullptr, 0, T)
         if (din == 2) { if (hp) MDK_GEMM(8, true); else MDK_GEMM(8, false); }
         else { if (hp) MDK_GEMM(4, true); else MDK_GEMM(4, false); }
 #undef MDK_GEMM

@@ -94,12 +94,15 @@ struct RlFrontArgs {
 // HP: half precision (`TorchModel.half()`): conv2 as ONE fp16 product instead of the three of the
 // hi/lo split (the reference's own half mode runs these convolutions in fp16 under autocast).
 template <bool TILED, bool HP = false>
-__global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
+__global__ __launch_bounds__(256, 2) void k_rl_front(const RlFrontArgs A)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ytile[2 * kRlRows * kRlRowBytes];
-    __shared__ float feat[kRlRows][8];
-    __shared__ int fvalid[kRlRows];
-    __shared__ float emb_b[8][6], emb_s[3][6];
+    // conv1 is linear in its 7 | 8 inputs and the first six of them are (embedding of base) + (embedding of strand):
+    // their contribution + bias is a table over the <= 8 x 3 (base, strand) pairs, built once per work-group with
+    // the SAME fma chain the per-position loop used (b1, then features 0..5), so the results are bit-identical
+    __shared__ float tab1[8 * 3][kRlC];
+    __shared__ float fq[kRlRows], fdw[kRlRows];
+    __shared__ int fidx[kRlRows];              // (base, strand) pair of the row, -1 outside the window
     __shared__ int n_reads_s;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,22 +111,26 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
     const int p0 = blockIdx.x * kRlPos;
     const int n = lane & 15, g = lane >> 4;
 
-    if (tid < A.n_alpha * 6) emb_b[tid / 6][tid % 6] = A.base_emb[tid];
-    if (tid >= 64 && tid < 64 + 18) emb_s[(tid - 64) / 6][(tid - 64) % 6] = A.strand_emb[tid - 64];
     if (tid == 128) {
         int cnt = 0;
         for (int d = 0; d < A.Dp; ++d) cnt += A.mask[(size_t)b * A.Dp + d] != 0;
         n_reads_s = cnt;
     }
+    for (int e = tid; e < A.n_alpha * 3 * kRlC; e += 256) {
+        const int c = e % kRlC, pair = e / kRlC, bi = pair / 3, si = pair % 3;
+        float v = A.b1[c];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) v = fmaf(A.w1[c * 8 + f], A.base_emb[bi * 6 + f] + A.strand_emb[si * 6 + f], v);
+        tab1[pair][c] = v;
+    }
 
-    // conv1 rows of this thread's two adjacent channels (one 4-byte LDS store per fp16 pair)
+    // conv1 constants of this thread's two adjacent channels (one 4-byte LDS store per fp16 pair)
     const int ci = 2 * (tid & 63), rsel = tid >> 6;
-    float w1r[2][8], b1v[2], a1v[2], c1v[2];
+    float w6[2], w7[2], a1v[2], c1v[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int f = 0; f < 8; ++f) w1r[j][f] = A.w1[(ci + j) * 8 + f];
-        b1v[j] = A.b1[ci + j]; a1v[j] = A.a1[ci + j]; c1v[j] = A.c1[ci + j];
+        w6[j] = A.w1[(ci + j) * 8 + 6]; w7[j] = A.w1[(ci + j) * 8 + 7];
+        a1v[j] = A.a1[ci + j]; c1v[j] = A.c1[ci + j];
     }
     // epilogue constants of this lane's conv2 / linear output columns: co = 32w + 16nt + n
     float b2v[2], a2v[2], c2v[2];
@@ -141,41 +148,56 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
 
     const unsigned char *xb = A.x + (size_t)b * A.P * A.Dp * A.F;
     unsigned char *yhi = ytile, *ylo = ytile + kRlRows * kRlRowBytes;
+    constexpr int NS = HP ? 1 : 2;
+    constexpr int kSteps = kRlTaps * 4;            // k-steps of conv2: (tap, 32-channel block)
+    // W2 fragments of k-step i: [i][4 waves][2 nt][2 hi/lo][64 lanes]
+    const half8 *wp = A.w2frag + (size_t)w * 4 * 64 + lane;
+    auto load_b = [&](int i, half8 (&dst)[2][NS]) {
+        const half8 *wk = wp + (size_t)i * (4 * 4 * 64);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) dst[nt][sp] = wk[(nt * 2 + sp) * 64];
+    };
+    const int a_lane = n * kRlRowBytes + (8 * g) * 2;
 
     for (int d = 0; d < A.Dp; ++d) {
         if (A.mask[(size_t)b * A.Dp + d] == 0) continue;   // uniform: empty reads contribute 0
-        // ---- 1a. features of the tile's positions (+ halo)
+        // ---- 1a. per-position inputs of the tile (+ halo): table row, q-score, dwell
         if (tid < kRlRows) {
             const int pp = p0 - kRlHalo + tid;
-            const bool ok = pp >= 0 && pp < A.P;
-            fvalid[tid] = ok;
-            float fv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ok) {
+            int idx = -1;
+            float q = 0.f, dw = 0.f;
+            if (pp >= 0 && pp < A.P) {
                 const unsigned char *xr = xb + ((size_t)pp * A.Dp + d) * A.F;
                 int bi = xr[0];
                 if (bi >= A.n_alpha) bi = A.n_alpha - 1;
                 int si = (int)(signed char)xr[2] + 1;        // strand -1/0/+1 -> 0/1/2
                 si = si < 0 ? 0 : (si > 2 ? 2 : si);
-#pragma unroll
-                for (int e = 0; e < 6; ++e) fv[e] = emb_b[bi][e] + emb_s[si][e];
-                fv[6] = (float)xr[1] / 25.0f - 1.0f;
-                if (A.nf == 8) fv[7] = (float)xr[4];
+                idx = bi * 3 + si;
+                q = (float)xr[1] / 25.0f - 1.0f;
+                if (A.nf == 8) dw = (float)xr[4];
             }
-#pragma unroll
-            for (int f = 0; f < 8; ++f) feat[tid][f] = fv[f];
+            fidx[tid] = idx; fq[tid] = q; fdw[tid] = dw;
         }
+        // the W2 fragments of the first two k-steps of this read travel while conv1 runs
+        half8 bq[3][2][NS];
+        load_b(0, bq[0]);
+        load_b(1, bq[1]);
         __syncthreads();
         // ---- 1b. conv1 (k=1) + ReLU + BN1 -> fp16 hi/lo tile
         for (int r = rsel; r < kRlRows; r += 4) {
+            const int idx = fidx[r];
+            const float q = fq[r], dw = fdw[r];
+            const float2 t2 = *reinterpret_cast<const float2 *>(&tab1[idx < 0 ? 0 : idx][ci]);
             half2_t hi2, lo2;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float v = b1v[j];
-#pragma unroll
-                for (int f = 0; f < 8; ++f) v = fmaf(w1r[j][f], feat[r][f], v);
+                float v = fmaf(w6[j], q, j ? t2.y : t2.x);
+                v = fmaf(w7[j], dw, v);
                 v = fmaxf(v, 0.f);
                 v = fmaf(a1v[j], v, c1v[j]);
-                if (!fvalid[r]) v = 0.f;                     // zero padding of conv2's input
+                if (idx < 0) v = 0.f;                        // zero padding of conv2's input
                 _Float16 hi, lo;
                 split_f16(v * A.s1, hi, lo);
                 hi2[j] = hi; lo2[j] = lo;
@@ -184,41 +206,56 @@ __global__ __launch_bounds__(256, 1) void k_rl_front(const RlFrontArgs A)
             if constexpr (!HP) *reinterpret_cast<half2_t *>(ylo + r * kRlRowBytes + ci * 2) = lo2;
         }
         __syncthreads();
-        // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks
+        // ---- 2. conv2 as implicit GEMM: acc[mt][nt] over 17 taps x 4 channel blocks = 68 k-steps.
+        // Software pipeline (round 3; the ISA of the round-2 loop waited a full L2 round trip for the four
+        // fragment loads of EVERY k-step and an LDS round trip for every M-tile: one wave kept the pipe ~32 % busy,
+        // two per SIMD 70 %): the W2 fragments of k-step i+2 are requested before the MFMAs of k-step i (a ring of
+        // three register sets: two k-steps = 72 MFMAs of cover for the L2 latency), the A fragments of the next
+        // M-tile before the MFMAs of the current one.  Every accumulator still receives its MFMAs in the same
+        // order: bit-identical results.
         floatx4 acc[kRlMT][2];
 #pragma unroll
         for (int mt = 0; mt < kRlMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        const half8 *wp = A.w2frag + (size_t)w * 4 * 64 + lane;
-#pragma unroll 1
-        for (int tau = 0; tau < kRlTaps; ++tau) {
+        auto a_off = [&](int i) { return a_lane + (i >> 2) * kRlRowBytes + (32 * (i & 3)) * 2; };
+        half8 ah = *reinterpret_cast<const half8 *>(yhi + a_off(0)), al;
+        if constexpr (!HP) al = *reinterpret_cast<const half8 *>(ylo + a_off(0));
+        // k-step i: fragments bb (requested two k-steps ago), request those of k-step i + 2 into bn
+        auto kstep = [&](int i, const half8 (&bb)[2][NS], half8 (&bn)[2][NS]) {
+            load_b(i + 2 < kSteps ? i + 2 : kSteps - 1, bn);   // (the last two re-request the last block)
+            __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of this k-step's MFMAs
+            const int off0 = a_off(i), off1 = a_off(i + 1 < kSteps ? i + 1 : i);
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                half8 bh[2], bl[2];
-                const half8 *wk = wp + (size_t)(tau * 4 + kb) * (4 * 4 * 64);
+            for (int mt = 0; mt < kRlMT; ++mt) {
+                // A fragments of the next M-tile (or of the next k-step's first one) before this tile's MFMAs
+                const int noff = (mt + 1 < kRlMT) ? off0 + 16 * (mt + 1) * kRlRowBytes : off1;
+                const half8 nah = *reinterpret_cast<const half8 *>(yhi + noff);
+                half8 nal;
+                if constexpr (!HP) nal = *reinterpret_cast<const half8 *>(ylo + noff);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    bh[nt] = wk[(nt * 2 + 0) * 64];
-                    if constexpr (!HP) bl[nt] = wk[(nt * 2 + 1) * 64];
-                }
-#pragma unroll
-                for (int mt = 0; mt < kRlMT; ++mt) {
-                    const int off = (16 * mt + n + tau) * kRlRowBytes + (32 * kb + 8 * g) * 2;
-                    const half8 ah = *reinterpret_cast<const half8 *>(yhi + off);
-                    half8 al;
-                    if constexpr (!HP) al = *reinterpret_cast<const half8 *>(ylo + off);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-                        if constexpr (!HP) {
-                            acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                            acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
-                        }
+                    acc[mt][nt] = mfma16(ah, bb[nt][0], acc[mt][nt]);
+                    if constexpr (!HP) {
+                        acc[mt][nt] = mfma16(al, bb[nt][0], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bb[nt][1], acc[mt][nt]);
                     }
                 }
+                ah = nah; al = nal;
+                __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, HP ? 2 : 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        static_assert(kSteps == 68, "the three-deep fragment ring below is written for 68 k-steps (66 + 2)");
+#pragma unroll 1
+        for (int i = 0; i < 66; i += 3) {
+            kstep(i, bq[0], bq[2]);
+            kstep(i + 1, bq[1], bq[0]);
+            kstep(i + 2, bq[2], bq[1]);
         }
+        kstep(66, bq[0], bq[2]);
+        kstep(67, bq[1], bq[0]);
         __syncthreads();   // everybody is done reading the conv1 tile
         // ---- 3. bias + ReLU + BN2, accumulated over the reads in registers
 #pragma unroll
