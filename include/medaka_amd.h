@@ -262,6 +262,8 @@ int mdk_device_synchronize(int device);
 int mdk_selftest_mfma(int device, float *max_abs_err, int *subnormal_preserved);
 /* Test hook: occupy `blocks` CUs with a compute-bound loop of `iters` FMA pairs per lane (synchronous). */
 int mdk_selftest_burn(int device, int blocks, int iters);
+/* Test hook: hold `blocks` CUs exclusively (one work-group with `lds_bytes` of LDS each) for `milliseconds`.  Synchronous. */
+int mdk_selftest_hold(int device, int blocks, int milliseconds, int lds_bytes);
 
 const char *mdk_last_error(void);
 const char *mdk_version(void);

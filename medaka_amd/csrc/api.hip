@@ -1087,6 +1087,29 @@ extern "C" int mdk_selftest_burn(int device, int blocks, int iters) {
     return MDK_OK;
 }
 
+// Test hook: hold `blocks` CUs EXCLUSIVELY (one 512-thread work-group each with `lds_bytes` of LDS, e.g. 140 KB, so
+// that nothing else fits beside it) for `milliseconds` of wall clock.  Synchronous; tests/test_parity_gpu.py uses it from
+// a second thread as the tenant that leaves the LSTM(384) cluster recurrence fewer CUs than it needs.
+__global__ __launch_bounds__(512, 1) void k_hold(unsigned long long ticks) {
+    extern __shared__ unsigned char hold_lds[];
+    hold_lds[threadIdx.x] = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int mdk_selftest_hold(int device, int blocks, int milliseconds, int lds_bytes) {
+    if (blocks < 1 || milliseconds < 0 || milliseconds > 10000 || lds_bytes < 512 || lds_bytes > 160 * 1024)
+        return fail(MDK_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hold), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_hold, dim3(blocks), dim3(512), (size_t)lds_bytes, st, (unsigned long long)milliseconds * 100000ull);   // 100 MHz
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return fail(MDK_ERR_DEVICE, "hold kernel failed: %s", hipGetErrorString(e));
+    return MDK_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // MFMA self-test: D = A(16x32) B(32x16) with the fragment layout the kernels assume, on
 // asymmetric integer data (exact in fp16/fp32), plus an fp16-subnormal operand probe.

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int cluster = (idx / kWC) * 8 + xcd, member = idx % kWC;
     if (cluster >= n_clusters) return;
+    // a cluster of an EARLIER launch of this forward timed out: the forward is lost and will be re-run or reported;
+    // do not spend another handshake time-out on each of its remaining launches
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int c = lane & 15, g = lane >> 4;   // accumulator: rows 4g..4g+3 = gates of unit g, column c
     constexpr int NS = HP ? 1 : 2;          // fp16 pieces per operand
     constexpr int GW = HP ? 16 : 8;         // windows per group: column c = window (HP) or 2*window + {hi, lo}

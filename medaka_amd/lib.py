@@ -82,6 +82,7 @@ ABI = {
     "mdk_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
     "mdk_device_synchronize": (_i, [_i]),
     "mdk_selftest_burn": (_i, [_i, _i, _i]),
+    "mdk_selftest_hold": (_i, [_i, _i, _i, _i]),
     "mdk_selftest_mfma": (_i, [_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
     "mdk_last_error": (ctypes.c_char_p, []),
     "mdk_version": (ctypes.c_char_p, []),

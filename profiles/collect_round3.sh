@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence, run ON THE GPU BOX from the repo root:  bash profiles/collect_round3.sh <tag> [stage ...]
-# Stages: tests bench procs variants prof pmc (default: tests bench procs).  Writes gpurun_out/<tag>/...
+# Stages: tests bench procs variants rl soak prof pmc pmc_rl (default: tests bench procs).  Writes gpurun_out/<tag>/...
 set -u
 TAG=${1:-r3}; shift || true
 STAGES=${*:-tests bench procs}
@@ -53,13 +53,42 @@ if has variants; then
   timeout 150 python bench.py --batch 1000 --steps 3 --warmup 1 --cpu-budget 0 --loop-batches 0 > "$OUT/bench_B1000.json" 2>/dev/null
   timeout 200 python bench.py --batch 2000 --steps 2 --warmup 1 --cpu-budget 0 --loop-batches 0 --host-reps 3 > "$OUT/bench_B2000.json" 2>/dev/null
 fi
+if has rl; then
+  timeout 300 python bench.py --model rl384 --steps 3 --warmup 1 --cpu-budget 40 > "$OUT/bench_rl384_B100.json" 2> "$OUT/bench_rl384.log"
+  timeout 300 python bench.py --model rl128 --steps 3 --warmup 1 --cpu-budget 40 > "$OUT/bench_rl128_B100.json" 2> "$OUT/bench_rl128.log"
+  timeout 200 python bench.py --model rl384 --half --steps 3 --warmup 1 --cpu-budget 0 > "$OUT/bench_rl384_B100_half.json" 2>/dev/null
+  tail -2 "$OUT/bench_rl384.log"
+fi
+if has soak; then
+  timeout 300 python profiles/soak_wide.py 6 --compete > "$OUT/soak_wide.log" 2>&1
+  tail -3 "$OUT/soak_wide.log"
+fi
+if has pmc_rl; then
+  cd /tmp
+  for M in rl384 rl128; do
+    i=0
+    for PASS in "FETCH_SIZE" "WRITE_SIZE"; do
+      i=$((i+1))
+      timeout 200 rocprofv3 --pmc $PASS --output-format csv -d "$OUT/pmc_$M/pass$i" -o pmc -- \
+          python "$R/bench.py" --model $M --steps 1 --warmup 0 --cpu-budget 0 > "$OUT/pmc_${M}_pass$i.log" 2>&1
+    done
+    python "$R/profiles/traffic_rl.py" "$OUT/pmc_$M" $M 100 10000 50 "$OUT/traffic_rl.json"
+    rm -rf "$OUT/pmc_$M"
+  done
+  cd "$R"
+fi
 if has prof; then
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru" -o gru -- python "$R/bench.py" --device-only --steps 5 --warmup 2 > "$OUT/kt_gru.log" 2>&1
   cd "$R"
-  db=$(find "$OUT/kt_gru" -name "*_results.db" | head -1)
-  [ -n "$db" ] && python profiles/summarize.py "$db" "$OUT/kt_gru_kernel_stats.csv" > /dev/null
-  find "$OUT/kt_gru" -name "*.db" -delete
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_rl384" -o rl -- python "$R/bench.py" --model rl384 --steps 2 --warmup 1 --cpu-budget 0 > "$OUT/kt_rl384.log" 2>&1
+  cd "$R"
+  for d in kt_gru kt_rl384; do
+    db=$(find "$OUT/$d" -name "*_results.db" | head -1)
+    [ -n "$db" ] && python profiles/summarize.py "$db" "$OUT/${d}_kernel_stats.csv" > /dev/null
+    find "$OUT/$d" -name "*.db" -delete
+  done
 fi
 if has pmc; then
   cd /tmp

@@ -690,6 +690,39 @@ def test_wide_read_level_half_precision(B, P, D, wide):
     assert same >= emu["argmax_agreement"] - 0.01
 
 
+def test_wide_read_level_fails_fast_without_its_cus():
+    """The cluster recurrence needs 192 CUs at once.  While another tenant holds 160 of the 256 CUs exclusively the
+    clusters' placement handshake cannot complete: both tries (bounded at 50 ms of wall clock each, later launches of
+    a lost forward return at once) must end in MDK_ERR_DEVICE within a fraction of a second -- not after seconds of
+    spinning, never with a wrong result -- and the engine must work again as soon as the CUs are back."""
+    import threading
+    import time
+    kw = _wide_kw(True)
+    st = rl_oracle.synth_rl_state(seed=33, **kw)
+    x = rl_oracle.synth_reads(9, 1200, 4, use_dwells=True, seed=12)      # 1200 positions: chunked, 32 recurrence launches
+    e = engine.RlEngine(st, **kw)
+    ref = e.forward_host(x)
+    L = lib.load()
+    holder = threading.Thread(target=lambda: lib.check(L.mdk_selftest_hold(0, 160, 1500, 140 * 1024), "hold"))
+    holder.start()
+    time.sleep(0.3)
+    t0 = time.perf_counter()
+    try:
+        out, err = e.forward_host(x), None
+    except lib.EngineError as exc:
+        out, err = None, str(exc)
+    dt = time.perf_counter() - t0
+    holder.join()
+    print(f"forward next to a tenant holding 160 CUs: {'error after' if err else 'completed in'} {dt * 1e3:.0f} ms"
+          + (f" ({err[:90]}...)" if err else ""))
+    if err is None:                    # the tenant was scheduled elsewhere or had finished: then the bits must be right
+        assert np.array_equal(out, ref)
+    else:
+        assert "timed out" in err and dt < 1.0
+    assert np.array_equal(e.forward_host(x), ref)                         # CUs back: same bits as before
+    e.close()
+
+
 # ---- the model swap on the device: integration.convert, every family (VERDICT r2 weak #1) -----------------------
 import ref_standins  # noqa: E402
 
