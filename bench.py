@@ -298,6 +298,35 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
 RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
 
 
+def pmc_summary(n_cus_in_use, rec_avg_ms, traffic_bytes):
+    """What north_star asks beside the roofline fraction: matrix-pipe busy share and HBM GB/s of the dominant kernel,
+    from the committed counter summary of THIS build at 200 x 10000 (profiles/r3_pmc_step.csv: rocprofv3 --pmc passes of
+    `bench.py --device-only --steps 1`, summed over the step by profiles/pmc_step.py) and this run's launch time.
+    SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r3_pmc_step.csv")
+    try:
+        busy = active = 0.0
+        for row in csv.DictReader(open(path)):
+            fam = row["kernel_family"]
+            if fam.startswith("k_rec_mfma") and "fallback" not in fam:
+                if row["counter"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy += float(row["sum_over_step"])
+                elif row["counter"] == "GRBM_GUI_ACTIVE":
+                    active += float(row["sum_over_step"]) / 8.0
+        if not busy or not active:
+            return None
+        out = {"source": "profiles/r3_pmc_step.csv (B=200, T=10000, this build)",
+               "mfma_busy_pct_of_chip": 100.0 * busy / (active * 1024),
+               "mfma_busy_pct_on_cus_in_use": 100.0 * busy / (active * 4 * n_cus_in_use), "cus_in_use": n_cus_in_use}
+        if traffic_bytes:
+            out["hbm_gbps"] = traffic_bytes / (rec_avg_ms * 1e-3) / 1e9
+            out["hbm_frac_of_8tbps"] = out["hbm_gbps"] / 8000.0
+        return out
+    except Exception:
+        return None
+
+
 def rl_traffic(model, B, P, D):
     """HBM bytes of one k_rl_front launch from the committed PMC summary (profiles/traffic_rl.json: FETCH_SIZE x 2 +
     WRITE_SIZE, collected by profiles/collect_round3.sh at 100 x 10000 x 50), scaled by the read positions of this run."""
@@ -566,6 +595,7 @@ def main():
                       "kernel, whose rocprof durations add up to this span)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
+            "pmc": pmc_summary(100, rec_avg_ms, traffic) if (B == 200 and T == 10000 and not args.half) else None,
             "avg_launch_ms": rec_avg_ms, "launches_timed": len(rec_ms),
             "kernel_launches_per_step": eng.timing()["rec_launches"],
             "algorithmic_flop_per_launch": rec_flop,

@@ -691,8 +691,9 @@ def test_wide_read_level_half_precision(B, P, D, wide):
 
 
 def test_wide_read_level_fails_fast_without_its_cus():
-    """The cluster recurrence needs 192 CUs at once.  While another tenant holds 160 of the 256 CUs exclusively the
-    clusters' placement handshake cannot complete: both tries (bounded at 50 ms of wall clock each, later launches of
+    """The cluster recurrence needs every member of a cluster on a CU at the same time (192 CUs for a full batch, 24 for
+    the two clusters of this small one).  While another tenant holds 250 of the 256 CUs exclusively the clusters'
+    placement handshake cannot complete: both tries (bounded at 50 ms of wall clock each, later launches of
     a lost forward return at once) must end in MDK_ERR_DEVICE within a fraction of a second -- not after seconds of
     spinning, never with a wrong result -- and the engine must work again as soon as the CUs are back."""
     import threading
@@ -703,7 +704,7 @@ def test_wide_read_level_fails_fast_without_its_cus():
     e = engine.RlEngine(st, **kw)
     ref = e.forward_host(x)
     L = lib.load()
-    holder = threading.Thread(target=lambda: lib.check(L.mdk_selftest_hold(0, 160, 1500, 140 * 1024), "hold"))
+    holder = threading.Thread(target=lambda: lib.check(L.mdk_selftest_hold(0, 250, 1500, 140 * 1024), "hold"))
     holder.start()
     time.sleep(0.3)
     t0 = time.perf_counter()
@@ -713,7 +714,7 @@ def test_wide_read_level_fails_fast_without_its_cus():
         out, err = None, str(exc)
     dt = time.perf_counter() - t0
     holder.join()
-    print(f"forward next to a tenant holding 160 CUs: {'error after' if err else 'completed in'} {dt * 1e3:.0f} ms"
+    print(f"forward next to a tenant holding 250 CUs: {'error after' if err else 'completed in'} {dt * 1e3:.0f} ms"
           + (f" ({err[:90]}...)" if err else ""))
     if err is None:                    # the tenant was scheduled elsewhere or had finished: then the bits must be right
         assert np.array_equal(out, ref)
