@@ -12,6 +12,7 @@ from medaka_amd import engine, synth  # noqa: E402
 st = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained.npz")))
 e = engine.GruEngine(st)
 e.enable_timing(True)
+e.set_option("max_rows_per_pass", int(os.environ.get("MAX_ROWS", "0")))
 T = 10000
 base = synth.counts_windows(8, T, seed=3)
 for B in [int(a) for a in sys.argv[1:]] or [504, 1000, 1496, 2000]:
