@@ -62,6 +62,8 @@ def parse():
                          "over gloo (RCCL refuses two ranks on one device); the value is NOT a scaling measurement")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
+    ap.add_argument("--pinned-input", action="store_true",
+                    help="host-to-host batches from a page-locked input tensor (what medaka_amd's Batch.collate produces)")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
     ap.add_argument("--loop-batches", type=int, default=14,
                     help="batches of the fed loop (threaded loader -> collate -> predict_on_batch -> writer; 0 = skip)")
@@ -527,7 +529,10 @@ def main():
     # host tensor in -> host tensor out (what run_prediction's loop sees), every rank at once
     eng.enable_timing(False)
     from medaka_amd.torch_ext import Batch
-    xb = Batch(counts_matrix=torch.from_numpy(x_host))
+    x_cpu = torch.from_numpy(x_host)
+    if args.pinned_input:          # what the engine's Batch.collate hands over (page-locked); default: the reference's pageable tensor
+        x_cpu = x_cpu.pin_memory()
+    xb = Batch(counts_matrix=x_cpu)
     h2h = []
 
     def host_step():
@@ -567,7 +572,8 @@ def main():
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
             "ms_per_batch_median": 1e3 * h_med, "timed_batches": len(h2h), "warmup": 2,
             "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
-            "what": "model.predict_on_batch(Batch(counts_matrix=<pageable CPU tensor>)) -> CPU tensor, per rank, "
+            "input": "page-locked (engine collate)" if args.pinned_input else "pageable (reference collate)",
+            "what": "model.predict_on_batch(Batch(counts_matrix=<CPU tensor>)) -> CPU tensor, per rank, "
                     "median over the timed batches, max over ranks; x streams in and probabilities stream out in "
                     "time slabs under the recurrences (include/medaka_amd.h: mdk_gru_forward)",
             "unstreamed_ms_per_batch": 1e3 * statistics.median(plain),
