@@ -13,7 +13,14 @@ import numpy as np
 import torch
 
 # host threads of the batch assembly (MEDAKA_AMD_COLLATE_THREADS; the reference's Batcher is one thread)
-COLLATE_THREADS = max(1, int(os.environ.get("MEDAKA_AMD_COLLATE_THREADS", "4")))
+def _collate_threads():
+    try:
+        return max(1, min(64, int(os.environ.get("MEDAKA_AMD_COLLATE_THREADS", "4"))))
+    except ValueError:
+        return 4
+
+
+COLLATE_THREADS = _collate_threads()
 
 
 def _batch_buffer(shape, dtype):

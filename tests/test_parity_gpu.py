@@ -690,6 +690,33 @@ def test_wide_read_level_half_precision(B, P, D, wide):
     assert same >= emu["argmax_agreement"] - 0.01
 
 
+def test_wide_read_level_full_batch_properties():
+    """BASELINE config 4b at full size: rl_lstm384 architecture, 100 windows x 10 000 positions x 50 reads (250 MB of
+    uint8).  Size-independent properties -- finite softmax rows; windows are independent, so permuting or splitting
+    the batch permutes / selects the output bit for bit (different cluster groups, different recurrence chunks) --
+    and ONE whole window (4 x 10 000 dependent LSTM steps) against the CPU oracle."""
+    kw = _wide_kw(True)
+    st = rl_oracle.synth_rl_state(seed=33, **kw)
+    B, P, D = 100, 10000, 50
+    base = rl_oracle.synth_reads(10, P, D, use_dwells=True, seed=70)
+    x = np.concatenate([base] * 10)
+    for b in range(B):                                                 # make the ten copies of a window distinct
+        x[b, (b * 37) % P, ::7, 1] ^= np.uint8(1 + b % 7)
+    e = engine.RlEngine(st, **kw)
+    out = e.forward_host(x)
+    assert out.shape == (B, P, 5) and np.isfinite(out).all()
+    assert np.abs(out.sum(-1) - 1).max() <= 2e-6
+    perm = np.random.default_rng(1).permutation(B)
+    assert np.array_equal(e.forward_host(x[perm]), out[perm])
+    assert np.array_equal(e.forward_host(x[:37]), out[:37])
+    assert np.array_equal(e.forward_host(x), out)                      # deterministic
+    e.close()
+    ref = rl_oracle.rl_forward(x[5:6], st, use_dwells=True, bidirectional=False)
+    err = float(np.abs(out[5:6] - ref).max())
+    print(f"rl_lstm384 full batch, window 5 (10 000 positions x 50 reads) vs the oracle: max|dp| = {err:.2e}")
+    _check(out[5:6], ref, what="rl_lstm384 full-size window")
+
+
 def test_wide_read_level_fails_fast_without_its_cus():
     """The cluster recurrence needs every member of a cluster on a CU at the same time (192 CUs for a full batch, 24 for
     the two clusters of this small one).  While another tenant holds 250 of the 256 CUs exclusively the clusters'
