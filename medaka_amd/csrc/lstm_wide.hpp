@@ -78,9 +78,10 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     unsigned long long *exch,           // [clusters][2 groups][2 parity][8 windows][384 units] granules + headers, zeroed
     int *status,                        // [0] != 0: a cluster timed out
     int B, int T, int reverse, float inv_scale, int n_clusters, int n_units, int force_wt, int poll_delay,
-    int s0, int ns, float *__restrict__ cstate)   // scan steps [s0, s0 + ns); s0 > 0 resumes from the h this
+    int s0, int ns, float *__restrict__ cstate,   // scan steps [s0, s0 + ns); s0 > 0 resumes from the h this
                                                   // kernel stored at scan step s0 - 1 and the cell state in
                                                   // cstate [B][384], which every launch leaves behind
+    int skip_if_lost)                             // synchronous forwards: return at once when status[0] is already up
 {
     __shared__ __attribute__((aligned(16))) unsigned char img[2][2][kWImgBytes];   // [group][parity]
     __shared__ int s_abort[2];
@@ -92,8 +93,9 @@ __global__ __launch_bounds__(512, 1) void k_lstm_wide(
     const int cluster = (idx / kWC) * 8 + xcd, member = idx % kWC;
     if (cluster >= n_clusters) return;
     // a cluster of an EARLIER launch of this forward timed out: the forward is lost and will be re-run or reported;
-    // do not spend another handshake time-out on each of its remaining launches
-    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    // do not spend another handshake time-out on each of its remaining launches.  (Not in asynchronous mode, where
+    // the flag of an earlier forward stays up until the caller asks with mdk_rl_check: later forwards must still run.)
+    if (skip_if_lost && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int c = lane & 15, g = lane >> 4;   // accumulator: rows 4g..4g+3 = gates of unit g, column c
     constexpr int NS = HP ? 1 : 2;          // fp16 pieces per operand
     constexpr int GW = HP ? 16 : 8;         // windows per group: column c = window (HP) or 2*window + {hi, lo}

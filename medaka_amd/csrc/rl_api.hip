@@ -537,7 +537,7 @@ static int rl_forward_wide_once(mdk_rl *m, const unsigned char *x_dev, int B, in
 #define MDK_WIDE_N(NG, HPF, ABLV)                                                                        \
     hipLaunchKernelGGL((k_lstm_wide<MDK_WIDE_PF, NG, HPF, ABLV>), dim3(rec_grid), dim3(512), 0, s, gi_cur, Ld.whh_frag, \
                        outp, m->exch, m->status, B, P, Ld.reverse, Ld.inv_rec, n_clusters, n_units, m->opt_force_wt, \
-                       hp ? 2 * m->opt_poll_delay : m->opt_poll_delay, s0, s1 - s0, m->cstate)   /* half: fewer MFMAs, later stores */
+                       hp ? 2 * m->opt_poll_delay : m->opt_poll_delay, s0, s1 - s0, m->cstate, m->opt_async ? 0 : 1)   /* half: fewer MFMAs, later stores */
 #define MDK_WIDE(ABLV)                                                                                   \
     do {                                                                                                 \
         if (hp) { if (ngrp == 2) MDK_WIDE_N(2, true, ABLV); else MDK_WIDE_N(1, true, ABLV); }            \
