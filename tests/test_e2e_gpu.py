@@ -218,3 +218,36 @@ def test_writer_thread_holds_rows_of_earlier_batches(model):
     later = {model.predict_on_batch(batches[0]).untyped_storage().data_ptr() for _ in range(4)}
     print(f"held blocks {len(set(storages))}, blocks seen after release {len(later)}")
     assert later & set(storages) or len(later) <= 2
+
+
+def test_processes_sharing_the_gpu_return_the_same_bits(gold, model, tmp_path):
+    """`launch.py --procs-per-gpu K`: K independent processes on ONE GPU, each told its share
+    (MEDAKA_AMD_PROCS_PER_GPU -> engine option gpu_share -> 8-window work-groups where 4-window ones of all K
+    would not fit the chip).  Three concurrent children must each return, batch after batch, exactly the bits
+    a process that has the GPU to itself returns."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from medaka_amd import synth
+    x = synth.counts_windows(8, 1024, depth=50, seed=321)
+    x = np.concatenate([x] * 30)                                   # 240 windows: 120 work-groups of 4 alone, 60 of 8 under sharing
+    np.save(tmp_path / "x.npy", x)
+    want = model.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+    child = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from medaka_amd import models\n"
+        "from medaka_amd.torch_ext import Batch\n"
+        f"st = dict(np.load({os.path.join(GOLD, 'weights_trained.npz')!r}))\n"
+        "m = models.GRUModel(); m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}); m = m.to('cuda').eval()\n"
+        "assert models.gpu_share() == 3\n"
+        "x = torch.from_numpy(np.load(sys.argv[1]))\n"
+        "outs = [m.predict_on_batch(Batch(counts_matrix=x)).numpy().copy() for _ in range(6)]\n"
+        "assert all(np.array_equal(o, outs[0]) for o in outs)\n"
+        "np.save(sys.argv[2], outs[-1])\n")
+    env = dict(os.environ, MEDAKA_AMD_PROCS_PER_GPU="3")
+    procs = [subprocess.Popen([sys.executable, "-c", child, str(tmp_path / "x.npy"), str(tmp_path / f"y{k}.npy")], env=env)
+             for k in range(3)]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0, 0]
+    for k in range(3):
+        assert np.array_equal(np.load(tmp_path / f"y{k}.npy"), want), k
