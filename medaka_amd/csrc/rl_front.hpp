@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_rl_front(const RlFrontArgs A)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
         auto a_off = [&](int i) { return a_lane + (i >> 2) * kRlRowBytes + (32 * (i & 3)) * 2; };
-        half8 ah = *reinterpret_cast<const half8 *>(yhi + a_off(0)), al;
+        half8 ah = *reinterpret_cast<const half8 *>(yhi + a_off(0)), al = ah;
         if constexpr (!HP) al = *reinterpret_cast<const half8 *>(ylo + a_off(0));
         // k-step i: fragments bb (requested two k-steps ago), request those of k-step i + 2 into bn
         auto kstep = [&](int i, const half8 (&bb)[2][NS], half8 (&bn)[2][NS]) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_rl_front(const RlFrontArgs A)
                 // A fragments of the next M-tile (or of the next k-step's first one) before this tile's MFMAs
                 const int noff = (mt + 1 < kRlMT) ? off0 + 16 * (mt + 1) * kRlRowBytes : off1;
                 const half8 nah = *reinterpret_cast<const half8 *>(yhi + noff);
-                half8 nal;
+                half8 nal = nah;                               // (half mode: never used)
                 if constexpr (!HP) nal = *reinterpret_cast<const half8 *>(ylo + noff);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
