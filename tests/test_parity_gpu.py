@@ -746,7 +746,7 @@ def test_wide_read_level_fails_fast_without_its_cus():
     if err is None:                    # the tenant was scheduled elsewhere or had finished: then the bits must be right
         assert np.array_equal(out, ref)
     else:
-        assert "timed out" in err and dt < 1.0
+        assert "timed out" in err and dt < 2.5       # two bounded tries, not seconds of spinning per launch
     assert np.array_equal(e.forward_host(x), ref)                         # CUs back: same bits as before
     e.close()
 
