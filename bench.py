@@ -62,6 +62,7 @@ def parse():
                          "over gloo (RCCL refuses two ranks on one device); the value is NOT a scaling measurement")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
+    ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default) or one copy each side (0)")
     ap.add_argument("--pinned-input", action="store_true",
                     help="host-to-host batches from a page-locked input tensor (what medaka_amd's Batch.collate produces)")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
@@ -540,6 +541,8 @@ def main():
         out_holder["p"] = model.predict_on_batch(xb)
         h2h.append(time.perf_counter() - t0)
     log('host-to-host batches')
+    if args.stream_host is not None:
+        eng.set_option("stream_host", args.stream_host)
     h_elapsed, _ = dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
     h2h = h2h[2:]
     h_med = ranks.max_over_ranks(statistics.median(h2h))
