@@ -20,6 +20,10 @@
 #include "common.hpp"
 #include "layout.hpp"
 
+#ifndef MDK_REC_PRIO
+#define MDK_REC_PRIO 3      // wave priority of the recurrence kernels (0..3)
+#endif
+
 namespace mdk {
 
 
@@ -72,6 +76,13 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
     // fused/unfused layer-0 selection is made on the device (input range flag of k_pack_x)
     if (cond != nullptr && ((*cond != 0) != (want != 0))) return;
+    // The recurrence is a chain of 2 x T dependent steps: whatever else is resident on this CU -- the side-stream
+    // projection / head / pack kernels of this forward, or another process's kernels under `launch.py
+    // --procs-per-gpu`, or a foreign tenant -- must not win instruction-issue arbitration against it.  Measured (round 3,
+    // profiles/r3_experiments/README.md): next to a co-resident kernel that issues MFMAs back to back on every SIMD the
+    // forward takes 29 ms at priority 0 and 19 ms at priority 3 (what is left is the clock dropping under the extra
+    // load); alone, and with K of our own processes sharing the GPU, nothing changes (A/B within one box).
+    __builtin_amdgcn_s_setprio(MDK_REC_PRIO);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
