@@ -148,8 +148,14 @@ def run(jobs, poll_s=0.5, log_dir=None):
             full_env = dict(os.environ, **env)
             full_env.pop("CUDA_VISIBLE_DEVICES", None)       # one selector only: HIP_VISIBLE_DEVICES
             log = open(os.path.join(log_dir, f"shard_{env.get('MEDAKA_AMD_SHARD', k)}.log"), "w") if log_dir else None
-            procs.append((subprocess.Popen(argv, env=full_env, stdout=log, stderr=subprocess.STDOUT if log else None,
-                                           start_new_session=True), log))
+            try:
+                child = subprocess.Popen(argv, env=full_env, stdout=log, stderr=subprocess.STDOUT if log else None,
+                                         start_new_session=True)
+            except BaseException:
+                if log:
+                    log.close()
+                raise
+            procs.append((child, log))
         while any(c is None for c in codes):
             for k, (p, _) in enumerate(procs):
                 if codes[k] is None:
