@@ -410,7 +410,7 @@ def main_rl(args):
                      "algorithmic_flop_per_launch": flop,
                      "note": f"algorithmic = conv2 only, {RL_CONV2_FLOP} FLOP per (window, read, position); peak = fp16 dense "
                              f"{PEAK_F16_DENSE_TFLOPS:.0f} TFLOP/s / {issue} fp16 products issued per algorithmic MAC; a register-only MFMA loop "
-                             "on all SIMDs sustains 0.64-0.67 of that nominal rate on this chip (profiles/probes/mfma_burn.hip), "
+                             "on all SIMDs sustains 0.81 (4 s) to 0.64-0.67 (25 s) of the nominal rate on this chip (profiles/probes/mfma_burn*.hip), "
                              "the kernel's matrix pipe is 81 % busy at a power-limited 1.69 GHz (profiles/r3_experiments/front/)",
                      "kernel_ms_per_step": {"front": statistics.mean(front), "device_total": statistics.mean(total)},
                      "wide_retries": eng.timing()["wide_retries"]},
