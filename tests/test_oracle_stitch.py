@@ -101,6 +101,34 @@ def test_goldens_regenerate_from_the_live_reference(sgold, gold):
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present (GPU box)")
+def test_engine_collate_inside_the_unmodified_run_prediction(sgold, gold):
+    """`integration.install()` replaces the counts branch of the reference's `Batch.collate`; the UNMODIFIED
+    `run_prediction` (threaded DataLoader -> Batcher thread -> collate -> predict_on_batch, prediction.py:36-60,
+    225-370) run with it must produce the committed FASTQ, junctions and samples byte for byte."""
+    from medaka_amd import integration, torch_ext
+    from oracle import make_golden_stitch as mg
+    ref_shim.install()
+    calls = []
+    real = torch_ext.stack_counts
+
+    def spy(feats, threads=None):
+        calls.append(len(feats))
+        return real(feats, threads)
+    integration.install(collate=True)
+    torch_ext.stack_counts, restore = spy, real
+    try:
+        import medaka.torch_ext as rte
+        rte.Batch.collate = classmethod(integration._fast_collate(integration._ORIG["collate"].__func__))   # bind the spy
+        out = mg.run_case("mini", mg.CASES["mini"], gold["weights_trained"])
+    finally:
+        torch_ext.stack_counts = restore
+        integration.uninstall()
+    assert sum(calls) > 0, "the patched collate was never called by the reference's Batcher thread"
+    for key in ("mini/fastq", "mini/junctions", "mini/trimmed", "mini/trim_last"):
+        assert np.array_equal(out[key], sgold[key]), key
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present (GPU box)")
 def test_restated_relationship_and_overlap_against_live_reference(sgold):
     """Sample.relative_position / overlap_indices on pairs drawn from the golden pileups, including
     reversed, contained, abutting and gapped pairs."""
