@@ -102,7 +102,9 @@ def region_pileups(common, sources, region, jitter=False):
     return out
 
 
-def run_case(name, spec, state):
+def run_case(name, spec, state, model=None):
+    """`model`: the object handed to the unmodified `run_prediction` in place of the reference's own GRUModel (tests pass
+    the engine-backed class with a CPU stand-in for the device); default: the reference model on PyTorch-CPU."""
     arch, models, te = ref_shim.reference_modules()
     import medaka.common as common
     import medaka.datastore
@@ -139,8 +141,9 @@ def run_case(name, spec, state):
                 # label_probs arrive as torch tensors (prediction.py:47-51) and come back from HDF5 as arrays
                 MemStore.samples.append(sample.amend(label_probs=np.array(sample.label_probs.numpy())))
 
-    model = arch.GRUModel(num_features=10, num_classes=5, gru_size=128).eval()
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    if model is None:
+        model = arch.GRUModel(num_features=10, num_classes=5, gru_size=128).eval()
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     seen_batches = []
     orig_predict = model.predict_on_batch
 

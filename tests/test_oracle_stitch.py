@@ -129,6 +129,48 @@ def test_engine_collate_inside_the_unmodified_run_prediction(sgold, gold):
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present (GPU box)")
+def test_engine_model_class_inside_the_unmodified_run_prediction(sgold, gold, monkeypatch):
+    """The engine-backed `medaka_amd.models.GRUModel` -- the object `integration.convert` hands to medaka -- driven by
+    the UNMODIFIED `run_prediction` (batched pass + B = 1 remainder pass), its rows written through `Sample.amend` /
+    `write_sample` and stitched by the reference's own code: with the device replaced by the CPU oracle (no GPU in the
+    build container; the kernels' own parity is the GPU suite's job) the FASTQ must be the committed one.  What this
+    pins is the plumbing: `Batch` handling, `get_model_input_features`, the host path's pointer / shape contract, the
+    returned tensor's life in the writer."""
+    import ctypes
+    import torch
+    from medaka_amd import models as amd_models
+    from oracle import make_golden_stitch as mg
+    from oracle import oracle as cpu_oracle
+    cpu = cpu_oracle.make_torch_oracle(gold["weights_trained"])
+    calls = []
+
+    class OracleDevice:
+        """Stands where `engine.GruEngine` stands: same `forward_ptr(x_ptr, B, T, out_ptr, host=True)` contract."""
+        def set_precision(self, half): assert not half
+        def set_variant(self, v): pass
+        def set_normalise(self, n): assert n
+        def set_option(self, k, v): pass
+        def close(self): pass
+
+        def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
+            assert host and stream is None
+            x = np.ctypeslib.as_array(ctypes.cast(x_ptr, ctypes.POINTER(ctypes.c_float)), shape=(B, T, 10))
+            out = np.ctypeslib.as_array(ctypes.cast(out_ptr, ctypes.POINTER(ctypes.c_float)), shape=(B, T, 5))
+            out[...] = cpu.predict(x.copy()).numpy()
+            calls.append((B, T))
+    m = amd_models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    m.eval()
+    dev = OracleDevice()
+    monkeypatch.setattr(amd_models.GRUModel, "engine", lambda self: dev)
+    out = mg.run_case("mini", mg.CASES["mini"], gold["weights_trained"], model=m)
+    assert len(calls) >= 3 and any(b == 1 for b, _ in calls)               # batched pass and B = 1 remainders
+    for key in ("mini/fastq", "mini/junctions", "mini/trimmed", "mini/trim_last"):
+        assert np.array_equal(out[key], sgold[key]), key
+    assert out["mini/batches"].tolist() == sgold["mini/batches"].tolist()
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present (GPU box)")
 def test_restated_relationship_and_overlap_against_live_reference(sgold):
     """Sample.relative_position / overlap_indices on pairs drawn from the golden pileups, including
     reversed, contained, abutting and gapped pairs."""
