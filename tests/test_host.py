@@ -398,6 +398,50 @@ def test_convert_engine_rejection_is_loud_in_strict_mode(monkeypatch):
         integration.convert(ref, device="cuda", strict=True)
 
 
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+@pytest.mark.parametrize("name", ["GRUModel", "rl_lstm384_no_dwells"])
+def test_install_swaps_the_model_inside_the_reference_load_model(name, tmp_path, monkeypatch):
+    """The whole reference flow of `ModelStoreTGZ.load_model(device=cuda)` (datastore.py:135-157: unpack, the pickled
+    `partial(model_from_dict, ...)`, `load_state_dict(torch.load(weights.pt))`, `.to(device)`, `.eval()`) with
+    `integration.install()` active in strict mode: what comes back is the engine-backed class with the archive's
+    weights.  Only the two steps that need a HIP device are stubbed (`Module.to`, `_finalise`)."""
+    import functools
+    import pickle
+    import tarfile
+    ref_shim.install()
+    import medaka.architectures as arch
+    import medaka.datastore as ds
+    import medaka.models as ref_models
+    from medaka_amd import integration
+    cls, kw = ref_standins.CONFIGS[name]
+    ref = getattr(arch, cls.__name__)(**kw)
+    _randomise(ref, 9)
+    top = tmp_path / "model"
+    top.mkdir()
+    torch.save(ref.state_dict(), top / "weights.pt")
+    with open(top / "meta.pkl", "wb") as fh:
+        pickle.dump({"model_function": functools.partial(ref_models.model_from_dict, ref.to_dict())}, fh)
+    tgz = tmp_path / "toy_model_pt.tar.gz"
+    with tarfile.open(tgz, "w:gz") as tar:
+        tar.add(top, arcname="model")
+    moved = []
+    monkeypatch.setattr(torch.nn.Module, "to", lambda self, *a, **k: (moved.append(a), self)[1])
+    monkeypatch.setattr(integration, "_finalise", lambda new, dev, ref_model, strict: new.eval())
+    monkeypatch.setenv("MEDAKA_AMD", "strict")
+    integration.install(collate=False)
+    try:
+        with ds.ModelStoreTGZ(str(tgz)) as store:
+            model = store.load_model(device=torch.device("cuda"))
+            assert store.model is model
+    finally:
+        integration.uninstall()
+    assert type(model).__module__ == "medaka_amd.models" and type(model).__name__ == cls.__name__
+    assert moved and str(moved[0][0]) == "cuda"                      # the reference moved its own model first
+    for k, v in ref.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v), k
+    assert model.to_dict() == ref.to_dict()
+
+
 def _build_c_host(tmp_path):
     import subprocess
     from medaka_amd import build as _build
