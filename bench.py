@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--shared-gpu", action="store_true",
                     help="dry check of the N > 1 path on a 1-GPU box: every rank uses device 0, the timing barrier runs "
                          "over gloo (RCCL refuses two ranks on one device); the value is NOT a scaling measurement")
+    ap.add_argument("--procs-per-gpu", type=int, default=1,
+                    help="K > 1: re-launch as K ranks of `--shared-gpu` on ONE GPU (medaka_amd.launch --procs-per-gpu K): the line's "
+                         "`value` / `host_to_host` are the aggregates of the K processes, `n_gpus` counts the ranks")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
     ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default) or one copy each side (0)")
@@ -448,6 +451,24 @@ def main_rl(args):
 
 def main():
     args = parse()
+    if args.procs_per_gpu > 1 and "WORLD_SIZE" not in os.environ:
+        # convenience: one command for the K-processes-per-GPU measurement of profiles/r3_procs_per_gpu.txt
+        import subprocess
+        rest, skip = [], False
+        for a in sys.argv[1:]:
+            if skip:
+                skip = False
+            elif a in ("--procs-per-gpu", "--gpus"):
+                skip = True
+            elif not (a.startswith("--procs-per-gpu=") or a.startswith("--gpus=") or a == "--shared-gpu"):
+                rest.append(a)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.procs_per_gpu}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + args.procs_per_gpu), os.path.abspath(__file__),
+               "--shared-gpu", "--gpus", str(args.procs_per_gpu)] + rest
+        if os.environ.get("MDK_BENCH_DRY"):
+            print(" ".join(cmd))
+            raise SystemExit(0)
+        raise SystemExit(subprocess.call(cmd))
     if args.model != "gru":
         return main_rl(args)
     import numpy as np
@@ -560,6 +581,7 @@ def main():
     result = {
         "metric": "pileup columns/sec (consensus bi-GRU inference)",
         "value": value, "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
+        "procs_per_gpu": ranks.world if args.shared_gpu else 1,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
