@@ -273,15 +273,20 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
             "writer_submits_per_batch": batch_size if per_sample_submit else 1}
 
 
-def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
-    """`fed_loop` with the reference's collate and with the engine's (medaka_amd.torch_ext.stack_counts)."""
+def loop_windows(T, depth, seed, n_win=64):
+    """Overlapping row views of one region's feature array, as `Sample.chunks` makes them."""
     import numpy as np
-    from medaka_amd import synth, torch_ext
+    from medaka_amd import synth
     step = T - 1000                                  # chunk_len 10000, chunk_ovlp 1000 (medaka.py:266-272)
-    n_win = 64
     base = synth.counts_windows(8, step, depth=depth, seed=seed).reshape(-1, 10)
     region = np.concatenate([base] * (-(-((n_win - 1) * step + T) // base.shape[0])))
-    windows = [region[i * step:i * step + T] for i in range(n_win)]    # overlapping views, like Sample.chunks
+    return [region[i * step:i * step + T] for i in range(n_win)]
+
+
+def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
+    """`fed_loop` with the reference's collate and with the engine's (medaka_amd.torch_ext.stack_counts)."""
+    from medaka_amd import torch_ext
+    windows = loop_windows(T, depth, seed)
     out = {"what": "sample workers -> Batcher thread (collate) -> model.predict_on_batch -> one-thread writer that copies "
                    "every row out; thread structure of reference prediction.py:36-60, 225-370",
            "batch_windows": B, "chunk_len": T}
@@ -606,7 +611,21 @@ def main():
             "unstreamed_ms_per_batch": 1e3 * statistics.median(plain),
         },
     }
+    shared_loop = None
+    if args.shared_gpu and ranks.world > 1 and args.loop_batches > 2:
+        # K processes per GPU, each running the whole fed loop (loader threads -> engine collate -> predict_on_batch ->
+        # writer): the deployment `medaka_amd.launch --procs-per-gpu K` produces; aggregate = sum over the processes
+        from medaka_amd import torch_ext
+        windows = loop_windows(T, args.depth, 4321 + ranks.rank)
+        fast = lambda data: torch_ext.Batch.collate(data)
+        fed_loop(model, windows, B, 3, fast, warm=1)
+        ranks.barrier()
+        mine_loop = fed_loop(model, windows, B, args.loop_batches, fast)
+        shared_loop = {"value": ranks.sum_over_ranks(mine_loop["value"]), "unit": "pileup columns/s", "processes": ranks.world,
+                       "rank0": mine_loop, "what": "every process runs the fed loop with the engine's collate; sum of their rates"}
     if ranks.rank == 0:
+        if shared_loop:
+            result["fed_loop_shared"] = shared_loop
         rec_avg_ms = statistics.mean(rec_ms)
         rec_flop = REC_FLOP_PER_COLUMN_LAYER * cols_per_step
         achieved = rec_flop / (rec_avg_ms * 1e-3) / 1e12
