@@ -68,6 +68,20 @@ typedef struct {
     int n_layers;
 } mdk_gru_timing;
 
+/* What the last forward did about splitting the scan (option "scan_split" below). */
+#define MDK_SPLIT_NOT_USED 0   /* shape not latency-bound, option off, or model outside the split path */
+#define MDK_SPLIT_CERTIFIED 1  /* ran as `chunks` chunks per window; every junction certified */
+#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-12): the call was repeated sequentially */
+#define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected: this model runs sequentially (auto mode) */
+typedef struct {
+    int chunks;       /* chunks per window of the last forward (1 = sequential scan) */
+    int margin;       /* warm-up columns on either side of a chunk */
+    int columns;      /* columns of one virtual window (T when not split) */
+    int status;       /* MDK_SPLIT_* */
+    float max_delta;  /* largest |h_warm - h_carried| over all certificate points of the last split forward */
+    int fallbacks;    /* rejected certificates since the model was created */
+} mdk_gru_split;
+
 /*
  * Replaces: `ModelStoreTGZ.load_model` -> `GRUModel(...)`; `load_state_dict`; `.to(device)`
  * (medaka/datastore.py:135-157, medaka/architectures/gru.py:46-56).
@@ -98,7 +112,8 @@ int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_
  * Same contraction with device-resident buffers (what `GRUModel.forward`, gru.py:58-72, is to
  * `predict_on_batch`).  x_dev / probs_dev are device pointers valid on the model's device;
  * `stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it, in order.
- * Asynchronous with respect to the host unless timing is enabled.
+ * Asynchronous with respect to the host unless timing is enabled or the call runs as a split scan ("scan_split":
+ * the certificate is read back, and a rejected call repeated, before the function returns).
  */
 int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
                         void *stream);
@@ -118,6 +133,15 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "deferred_store"       = 1 | 0                  recurrence: h_t leaves for HBM from inside step t+1 (default 1)
  *   "gpu_share"            = 1 .. 8                 processes sharing this GPU (medaka_amd.launch --procs-per-gpu):
  *                                                   work-group sizes are chosen so that all of them fit the chip
+ *   "scan_split"           = 1 (auto) | 0 | 2..16      split the scan: batches that leave most of the GPU idle (3 <= chunks <= 1024 / gpu_share / B) run as `chunks` chunks per window, each warmed up over
+ *                                                   "scan_split_margin" columns on either side, as ONE batch of
+ *                                                   B * chunks windows of about T / chunks + 2 * margin columns; the
+ *                                                   states at every junction are compared on the device (both layers,
+ *                                                   both directions, at the junction and margin / 2 columns past it) and
+ *                                                   the call is repeated as the sequential scan -- and, in auto mode,
+ *                                                   the model stays sequential -- if any differs by more than 2^-19 (2^-12 in half-precision mode).
+ *                                                   n >= 2 forces n chunks (bidirectional 2-layer models, T >= 8 * margin)
+ *   "scan_split_margin"    = 256 | multiple of 8 in 16..4096
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
@@ -132,6 +156,9 @@ int mdk_gru_debug_read(mdk_gru *m, unsigned long long *dst, int n);
 /* hipEvent timing of every kernel of the following forwards (adds a stream sync per forward). */
 int mdk_gru_enable_timing(mdk_gru *m, int on);
 int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);
+
+/* Chunks, margin and certificate of the last forward (see "scan_split"). */
+int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out);
 
 /* Device ordinal the model lives on (`TorchModel.device()`, models.py:291-296). */
 int mdk_gru_device(const mdk_gru *m);

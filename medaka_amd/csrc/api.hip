@@ -20,6 +20,7 @@
 #include "layout.hpp"
 #include "head.hpp"
 #include "rec_mfma.hpp"
+#include "scan_split.hpp"
 
 using namespace mdk;
 
@@ -87,6 +88,15 @@ struct mdk_gru {
     int opt_deferred_store = 1;              // recurrence: HBM store of h_t from inside step t+1 (rec_mfma.hpp DS)
     int opt_gpu_share = 1;                   // processes sharing this GPU (launch.py --procs-per-gpu): divides the CU budgets below
     int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
+    // split scan (scan_split.hpp)
+    int opt_scan_split = 1;                  // 0 off, 1 auto, n >= 2: n chunks per window whenever the shape allows it
+    int opt_split_margin = 256;              // G: columns of warm-up on either side of a chunk
+    bool split_disabled = false;             // a certificate failed: this model stays sequential (auto mode)
+    float *xv = nullptr, *pv = nullptr;      // virtual batch in, its probabilities out
+    size_t xv_cap = 0, pv_cap = 0;
+    unsigned *split_flag = nullptr;          // device: [0] certificate failed, [1] bits of the largest junction difference
+    unsigned *split_host = nullptr;          // page-locked copy of split_flag
+    mdk_gru_split last_split{};
     // timing
     bool timing = false;
     mdk_gru_timing last{};
@@ -103,6 +113,8 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
+    free_dev(m->xv); free_dev(m->pv); free_dev(m->split_flag);
+    if (m->split_host) (void)hipHostFree(m->split_host);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -316,6 +328,13 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "gpu_share")) {
         if (value < 1 || value > 8) return fail(MDK_ERR_ARG, "gpu_share must be 1..8");
         m->opt_gpu_share = value;
+    } else if (!strcmp(key, "scan_split")) {
+        if (value < 0 || value > kMaxSplit) return fail(MDK_ERR_ARG, "scan_split must be 0 (off), 1 (auto) or 2..%d chunks", kMaxSplit);
+        m->opt_scan_split = value;
+        m->split_disabled = false;           // setting the option re-arms a model that fell back
+    } else if (!strcmp(key, "scan_split_margin")) {
+        if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
+        m->opt_split_margin = value;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -337,6 +356,11 @@ extern "C" int mdk_gru_enable_timing(mdk_gru *m, int on) {
 extern "C" int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out) {
     if (!m || !out) return fail(MDK_ERR_ARG, "null argument");
     *out = m->last;
+    return MDK_OK;
+}
+extern "C" int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out) {
+    if (!m || !out) return fail(MDK_ERR_ARG, "null argument");
+    *out = m->last_split;
     return MDK_OK;
 }
 extern "C" int mdk_gru_device(const mdk_gru *m) { return m ? m->device : -1; }
@@ -531,6 +555,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
     const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
     const bool stream_out = io_out && can_chunk && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
+    const int F = m->desc.num_features, C = m->desc.num_classes;
+    // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
+    auto copy_in_cols = [&](int t0, int nt) -> int {
+        if (nt <= 0) return MDK_OK;
+        HIP_TRY(hipMemcpy2DAsync(const_cast<float *>(x) + (size_t)t0 * F, (size_t)T * F * sizeof(float),
+                                 io->x_host + (size_t)t0 * F, (size_t)T * F * sizeof(float),
+                                 (size_t)nt * F * sizeof(float), (size_t)nb, hipMemcpyHostToDevice, m->copy_in));
+        return MDK_OK;
+    };
     if (io_in && !stream_in)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x), io->x_host, x_bytes, hipMemcpyHostToDevice, s));
     const float *gi_l1 = m->gi;
@@ -545,15 +578,6 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         }
         gi_l1 = m->gi2;
     }
-    const int F = m->desc.num_features, C = m->desc.num_classes;
-    // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
-    auto copy_in_cols = [&](int t0, int nt) -> int {
-        if (nt <= 0) return MDK_OK;
-        HIP_TRY(hipMemcpy2DAsync(const_cast<float *>(x) + (size_t)t0 * F, (size_t)T * F * sizeof(float),
-                                 io->x_host + (size_t)t0 * F, (size_t)T * F * sizeof(float),
-                                 (size_t)nt * F * sizeof(float), (size_t)nb, hipMemcpyHostToDevice, m->copy_in));
-        return MDK_OK;
-    };
     struct OutRange { hipEvent_t ready; int t0, nt; };
     std::vector<OutRange> out_ranges;   // head chunks to copy out; issued after every launch is enqueued, because a
                                         // copy into pageable memory may block the calling thread until it is done
@@ -830,6 +854,123 @@ static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs
     return finish_timing(m, tm, s);
 }
 
+// ---- split scan (scan_split.hpp): plan, run on the virtual batch, certify, fall back
+static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
+    static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
+    p.S = 1;
+    if (m->opt_scan_split == 0 || (m->split_disabled && m->opt_scan_split == 1)) return false;
+    if (m->variant != MDK_VARIANT_MFMA || m->D != 2 || m->desc.num_layers != 2 || m->opt_ablate || env_abl) return false;
+    if (m->layers[0].K > 16) return false;
+    const int G = m->opt_split_margin;
+    // the recurrence holds 8 windows per work-group and direction at most (fp32-parity mode): 1024 virtual windows
+    // are one round of work-groups on 256 CUs -- more than that queues (profiles/r3_experiments/scan_split/time_probe.txt)
+    const int max_win = 1024 / m->opt_gpu_share;
+    int S = (m->opt_scan_split >= 2) ? m->opt_scan_split : max_win / std::max(B, 1);
+    if (m->opt_scan_split == 1 && S < 3) return false;   // two chunks of 500 windows: +8 % on the device, nothing host to host
+    S = std::min({S, kMaxSplit, T / (4 * G)});      // a chunk's own columns are at least twice its two margins
+    if (S < 2) return false;
+    p.S = S; p.B = B; p.T = T; p.G = G;
+    int max_core = 0;
+    for (int k = 0; k <= S; ++k) p.core0[k] = (int)((long)T * k / S);
+    for (int k = 0; k < S; ++k) max_core = std::max(max_core, p.core0[k + 1] - p.core0[k]);
+    p.Tv = (max_core + 2 * G + 15) / 16 * 16;
+    if (p.Tv >= T || (size_t)S * B * p.Tv > (m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass)) { p.S = 1; return false; }
+    for (int k = 0; k < S; ++k) p.start[k] = std::min(std::max(p.core0[k] - G, 0), T - p.Tv);
+    return true;
+}
+
+static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
+                     const float *x_host, float *probs_host, bool *certified) {
+    const size_t F = m->desc.num_features, C = m->desc.num_classes;
+    const int Bv = sp.S * sp.B;
+    const size_t cols = (size_t)Bv * sp.Tv;
+    memset(&m->last, 0, sizeof(m->last));
+    m->last.n_layers = m->desc.num_layers;
+    if (cols * F > m->xv_cap) {
+        free_dev(m->xv); m->xv = nullptr; m->xv_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->xv, cols * F * sizeof(float)));
+        m->xv_cap = cols * F;
+    }
+    if (cols * C > m->pv_cap) {
+        free_dev(m->pv); m->pv = nullptr; m->pv_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->pv, cols * C * sizeof(float)));
+        m->pv_cap = cols * C;
+    }
+    if (!m->split_flag) {
+        HIP_TRY(hipMalloc((void **)&m->split_flag, kSplitFlagWords * sizeof(unsigned)));
+        HIP_TRY(hipHostMalloc((void **)&m->split_host, kSplitFlagWords * sizeof(unsigned), hipHostMallocDefault));
+    }
+    int rc = ensure_workspace(m, (((size_t)Bv + kTileWin - 1) / kTileWin * kTileWin) * (size_t)sp.Tv);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(m->split_flag, 0, kSplitFlagWords * sizeof(unsigned), s));
+    // The host buffers cross PCIe whole, as one copy each way, around the device-resident split forward: the time-slab
+    // streaming of the sequential host path would have to copy S strided pieces per slab, and strided copies with
+    // short rows run at half the rate of a contiguous one (profiles/r3_experiments/scan_split/host_path.txt)
+    if (x_host)
+        HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
+    {
+        const int vec = (F % 2 == 0) ? 2 : 1;
+        const size_t n = cols * F / vec;
+        hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
+                           x_dev, m->xv, sp, (int)F, vec);
+    }
+    EvTimer tm{m, s};
+    rc = forward_pass(m, m->xv, Bv, sp.Tv, m->pv, s, tm, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_split_verify, dim3((unsigned)sp.B, (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
+                       (const float *)m->act[0], (const float *)m->act[1], sp,
+                       m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps, m->split_flag);
+    HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    {   // the device-resident result (mdk_gru_forward_dev; the host entries that decode on the device read it too)
+        const size_t n = (size_t)sp.B * sp.T * C;
+        hipLaunchKernelGGL(k_split_scatter, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
+                           (const float *)m->pv, probs_dev, sp, (int)C);
+    }
+    HIP_TRY(hipGetLastError());
+    if (probs_host)
+        HIP_TRY(hipMemcpyAsync(probs_host, probs_dev, (size_t)sp.B * sp.T * C * sizeof(float), hipMemcpyDeviceToHost, s));
+    if ((rc = finish_timing(m, tm, s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
+    float worst;
+    memcpy(&worst, &m->split_host[1], sizeof(float));
+    *certified = m->split_host[0] == 0;
+    static const bool dbg = getenv("MDK_SPLIT_DEBUG") != nullptr;
+    if (dbg) {
+        fprintf(stderr, "[mdk split] %d x %d as %d chunks of %d columns (margin %d): %s, worst %.3g\n", sp.B, sp.T, sp.S, sp.Tv, sp.G,
+                *certified ? "certified" : "REJECTED", worst);
+        for (int y = 0; y < 8 * (sp.S - 1); ++y) {
+            float d;
+            memcpy(&d, &m->split_host[2 + y], sizeof(float));
+            fprintf(stderr, "    junction %d (column %d) layer %d direction %d point %d: %.3g\n", y >> 3, sp.core0[(y >> 3) + 1], (y >> 2) & 1,
+                    (y >> 1) & 1, y & 1, d);
+        }
+    }
+    m->last_split.chunks = sp.S; m->last_split.margin = sp.G; m->last_split.columns = sp.Tv;
+    m->last_split.max_delta = worst;
+    m->last_split.status = *certified ? MDK_SPLIT_CERTIFIED : MDK_SPLIT_REJECTED;
+    return MDK_OK;
+}
+
+// one call: split scan when the shape is latency-bound and the certificate holds, the sequential passes otherwise
+static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
+                       const float *x_host, float *probs_host) {
+    SplitPlan sp;
+    m->last_split.chunks = 1; m->last_split.margin = 0; m->last_split.columns = T; m->last_split.max_delta = 0.f;
+    m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
+    if (plan_split(m, B, T, sp)) {
+        bool ok = false;
+        int rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
+        if (rc) return rc;
+        static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug: deliver a rejected split as it is
+        if (ok || keep) return MDK_OK;
+        // some junction did not merge (a model with a long or chaotic memory): the sequential scan decides, for this
+        // call and -- in auto mode -- for every later one
+        m->last_split.fallbacks++;
+        if (m->opt_scan_split == 1) m->split_disabled = true;
+    }
+    return run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
+}
+
 extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
                                    void *stream) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
@@ -838,7 +979,7 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
     // NULL = the legacy default stream, as for any HIP call
-    return run_passes(m, x_dev, B, T, probs_dev, (hipStream_t)stream, nullptr, nullptr);
+    return run_forward(m, x_dev, B, T, probs_dev, (hipStream_t)stream, nullptr, nullptr);
 }
 
 static int ensure_staging(mdk_gru *m, size_t nx, size_t np) {
@@ -865,7 +1006,7 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
     int rc = ensure_staging(m, nx, np);
     if (rc) return rc;
     // x streams in and the probabilities stream out while the recurrences run (forward_pass, HostIO)
-    rc = run_passes(m, m->x_dev, B, T, m->p_dev, m->stream, x_host, probs_host);
+    rc = run_forward(m, m->x_dev, B, T, m->p_dev, m->stream, x_host, probs_host);
     if (rc) { (void)hipDeviceSynchronize(); return rc; }   // nothing of ours may still touch the caller's buffers
     HIP_TRY(hipStreamSynchronize(m->stream));
     return MDK_OK;
@@ -929,7 +1070,7 @@ static int forward_any(mdk_gru *m, const float *x_host, const uint16_t *counts_h
         if (rc) return rc;
     }
     // float features stream in, probabilities (if wanted) stream out under the recurrences (HostIO)
-    int rc = run_passes(m, m->x_dev, B, T, m->p_dev, s, counts_host ? nullptr : x_host, probs_host);
+    int rc = run_forward(m, m->x_dev, B, T, m->p_dev, s, counts_host ? nullptr : x_host, probs_host);
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
     if (cls_host) {
         float *pm = reinterpret_cast<float *>(m->aux_dev);          // depth is dead by now

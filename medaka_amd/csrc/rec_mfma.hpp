@@ -131,10 +131,15 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const int t_first = reverse ? (T - 1 - s0) : s0;
     const float *gp[NQ];
     float *op[NQ];
+    bool live[NQ];
+    auto stores = [&](int q) { if constexpr (NQ == 4) return live[q]; else return true; };
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         int win = blockIdx.x * (4 * NQ) + NQ * g + q;
-        if (win >= n_tiles * kTileWin) win = n_tiles * kTileWin - 1;   // (only NQ = 4 can run past the padding)
+        // only NQ = 4 can run past the padding (a tile count that is odd): those lanes load from the last window, for
+        // the addresses' sake, and store nothing -- with the fused layer-0 input their x rows are zero, not a copy
+        live[q] = win < n_tiles * kTileWin;
+        if (!live[q]) win = n_tiles * kTileWin - 1;
         const int tile = win >> 3, wt = win & 7;
         const int llane = (wt >> 1) * 16 + c, lq = wt & 1;
         gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first, NG) + gi_in_block(w8, lq, 0, llane, NG);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         static_assert(!(DS && (ABL || CELL)), "deferred stores: GRU production builds only");
 #pragma unroll
                         for (int q = 0; q < NQ; ++q)
-                            if (step > s0 && step <= s_end) *(op[q] - ostride) = hprev[q];   // h of the previous step
+                            if (step > s0 && step <= s_end && stores(q)) *(op[q] - ostride) = hprev[q];   // h of the previous step
                     }
                     // --- scheduling fence: everything above (r,z tiles) is issued before the n tiles;
                     // the sigmoids of r,z below share a region with the n MFMAs and are interleaved
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                             const float h = ((rows(ar, q) + rows(az, q)) + (rows(anh, q) + rows(anl, q))) * 1e-6f +
                                             (rr[q] + zz[q] + gnv[q]) * 1e-9f;
                             hprev[q] = h; hn[q] = h;
-                            if constexpr (!(ABL & 16)) { if (step < s_end) op[q][0] = h; }
+                            if constexpr (!(ABL & 16)) { if (step < s_end && stores(q)) op[q][0] = h; }
                             continue;
                         }
                         float tn;
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
                         hprev[q] = h;
                         hn[q] = h;
-                        if constexpr (!(ABL & 16) && !DS) { if (step < s_end) op[q][0] = h; }
+                        if constexpr (!(ABL & 16) && !DS) { if (step < s_end && stores(q)) op[q][0] = h; }
                     }
                 } else {
                     // ---- LSTM cell: i, f, g tiles first; the o tile last, with the cell update
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
                         const float ov = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(to * c_sig));
                         const float h = ov * tc[q];
                         hn[q] = h;
-                        if (step < s_end) op[q][0] = h;
+                        if (step < s_end && stores(q)) op[q][0] = h;
                     }
                 }
                 if constexpr (ABL & 64) { asm volatile("" ::"v"(hn[0])); stamp(3); }   // MFMA drain + tanh/blend chain
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         // the loop runs whole groups of PF steps: when the last of them is step s_end - 1 nobody stored it yet
         if ((s_end - s0) % PF == 0) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) *(op[q] - ostride) = hprev[q];
+            for (int q = 0; q < NQ; ++q) if (stores(q)) *(op[q] - ostride) = hprev[q];
         }
     }
     if constexpr (ABL & 64) {

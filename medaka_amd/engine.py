@@ -134,6 +134,13 @@ class GruEngine:
                 "head_ms": t.head_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms,
                 "rec_launches": t.rec_launches}
 
+    def split(self):
+        """What the last forward did about splitting the scan (include/medaka_amd.h `mdk_gru_split`)."""
+        t = _lib.GruSplit()
+        _lib.check(_lib.load().mdk_gru_get_split(self._h, ctypes.byref(t)), "mdk_gru_get_split")
+        return {"chunks": t.chunks, "margin": t.margin, "columns": t.columns, "status": _lib.SPLIT_STATUS.get(t.status, t.status),
+                "max_delta": t.max_delta, "fallbacks": t.fallbacks}
+
     # -- compute
     def forward_host(self, x, out=None):
         """x: (B,T,F) float32 host array -> (B,T,C) float32 host array (synchronous)."""

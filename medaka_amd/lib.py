@@ -39,6 +39,14 @@ class GruTiming(ctypes.Structure):
                 ("rec_launches", ctypes.c_int), ("n_layers", ctypes.c_int)]
 
 
+class GruSplit(ctypes.Structure):
+    _fields_ = [("chunks", ctypes.c_int), ("margin", ctypes.c_int), ("columns", ctypes.c_int),
+                ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int)]
+
+
+SPLIT_STATUS = {0: "not used", 1: "certified", 2: "rejected", 3: "disabled"}
+
+
 # every symbol include/medaka_amd.h declares: (restype, argtypes)
 _vp, _i, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 ABI = {
@@ -52,6 +60,7 @@ ABI = {
     "mdk_gru_debug_read": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
+    "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),
     "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),
