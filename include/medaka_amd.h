@@ -141,7 +141,8 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   the call is repeated as the sequential scan -- and, in auto mode,
  *                                                   the model stays sequential -- if any differs by more than 2^-19 (2^-12 in half-precision mode).
  *                                                   n >= 2 forces n chunks (bidirectional 2-layer models, T >= 8 * margin)
- *   "scan_split_margin"    = 256 | multiple of 8 in 16..4096
+ *   "scan_split_margin"    = 256 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read when
+ *                                                   a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;

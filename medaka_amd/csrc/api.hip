@@ -147,6 +147,12 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->device = device;
     m->D = D;
     m->layers.resize(L);
+    // process-wide defaults of the split scan (the options of the same names override them per model)
+    if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
+    if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
+        const int g = atoi(e);
+        if (g >= 16 && g <= 4096 && g % 8 == 0) m->opt_split_margin = g;
+    }
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -1,0 +1,245 @@
+"""The split scan (medaka_amd/csrc/scan_split.hpp) at the product default: batches that leave the GPU idle run as S
+chunks per window; every junction is certified on the device and a rejected call is repeated sequentially.
+
+What is asserted:
+  * certified calls agree with the unmodified reference's goldens and with the CPU oracle to the parity tolerance
+    (2e-5, argmax identity) and with the engine's own sequential scan to 2e-6 (measured: 1e-7);
+  * models whose memory outlasts the margin (weights x3) or that never forget (x5) are REJECTED, the caller gets the
+    sequential scan's bits, and the model stays sequential afterwards (auto mode);
+  * host entry, device entry, counts / decoded entries and the model API all take the same path and agree bit for bit;
+  * shapes outside the split's envelope are left alone."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, usable_cores, weight_set
+from medaka_amd import engine, models, synth
+from medaka_amd.torch_ext import Batch
+from oracle import oracle
+from test_parity_gpu import _check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def product_default(monkeypatch):
+    """conftest pins the older tests to the sequential scan; here engines are created the way a user's are."""
+    monkeypatch.delenv("MDK_SCAN_SPLIT", raising=False)
+    monkeypatch.delenv("MDK_SCAN_SPLIT_MARGIN", raising=False)
+
+
+def _sequential(e, x):
+    e.set_option("scan_split", 0)
+    out = e.forward_host(x)
+    assert e.split()["status"] == "not used"
+    e.set_option("scan_split", 1)
+    return out
+
+
+def test_goldens_from_unmodified_reference_split(gold):
+    """Every 10 000-column golden of the unmodified reference, split (S = 9..16 at these batch sizes)."""
+    n = 0
+    for wname in ("init", "trained"):
+        e = engine.GruEngine(weight_set(gold, wname))
+        for key in sorted(gold["gru_outputs"]):
+            if key.split("/")[0] != wname:
+                continue
+            x = gold["gru_inputs"][key.split("/")[1]]
+            out = e.forward_host(x)
+            info = e.split()
+            if x.shape[1] >= 3072:
+                assert info["status"] == "certified" and info["chunks"] >= 3, (key, info)
+                assert info["max_delta"] <= 1.0e-6, (key, info)
+                n += 1
+            else:
+                assert info["status"] == "not used", (key, info)
+            _check(out, gold["gru_outputs"][key], what=f"{key} split {info}", strict_argmax=(wname == "trained"))
+        e.close()
+    assert n >= 1
+    # the adversarial 10 000-column goldens (oracle/make_golden_adversarial.py): whatever the certificate decides,
+    # the answer holds the contract tolerance against the unmodified reference
+    from oracle.make_golden_adversarial import adversarial_input, adversarial_state
+    adv = np.load(os.path.join(GOLD, "gru_adversarial.npz"))
+    for name in ("x5", "x1e-3", "range16", "saturated", "bigx"):
+        e = engine.GruEngine(adversarial_state(name, gold["weights_init"], gold["weights_trained"]))
+        out = e.forward_host(adversarial_input(name))
+        info = e.split()
+        e.close()
+        print(f"adversarial {name}: {info['status']} ({info['chunks']} chunks, largest junction difference "
+              f"{info['max_delta']:.2e}), max|dp| vs the reference {np.abs(out - adv[name]).max():.2e}")
+        assert info["status"] in ("certified", "rejected")
+        if name in ("x5", "saturated"):          # chaotic / saturated gates: these do not forget within the margin
+            assert info["status"] == "rejected", (name, info)
+        _check(out, adv[name], tol=1e-4, what=name, strict_argmax=name in ("range16", "saturated", "bigx"))
+
+
+def test_full_batch_split_vs_oracle_and_sequential(gold):
+    """BASELINE configs[1] (200 x 10000) at the product default: five chunks per window, certified; all 2 M columns
+    against the PyTorch-CPU oracle (2e-5, every argmax) and against the sequential scan of the same engine (2e-6)."""
+    B, T = 200, 10000
+    x = np.concatenate([synth.counts_windows(8, T, depth=50, seed=100 + s) for s in range(25)])
+    e = engine.GruEngine(gold["weights_trained"])
+    out = e.forward_host(x)
+    info = e.split()
+    assert info == {**info, "chunks": 5, "margin": 256, "status": "certified", "fallbacks": 0}, info
+    assert info["max_delta"] <= 1.0e-6
+    assert np.array_equal(e.forward_host(x), out)                         # deterministic
+    seq = _sequential(e, x)
+    d = float(np.abs(out - seq).max())
+    print(f"split (5 chunks, margin 256) vs sequential over {B * T} columns: max|dp| = {d:.2e}, largest junction "
+          f"difference {info['max_delta']:.2e}, argmax identical: {np.array_equal(out.argmax(-1), seq.argmax(-1))}")
+    assert d <= 2e-6
+    assert np.array_equal(out.argmax(-1), seq.argmax(-1))
+    torch.set_num_threads(usable_cores())
+    cpu = oracle.make_torch_oracle(gold["weights_trained"])
+    worst = 0.0
+    for lo in range(0, B, 50):
+        ref = cpu.predict(x[lo:lo + 50]).numpy()
+        worst = max(worst, float(np.abs(out[lo:lo + 50] - ref).max()))
+        _check(out[lo:lo + 50], ref, what=f"split full batch, windows {lo}..{lo + 49}", strict_argmax=True)
+    print(f"split full batch vs the PyTorch-CPU oracle over {B * T} columns: max|dp| = {worst:.2e}")
+    # device entry, page-locked buffers, counts and decoded entries: the same path, the same bits
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty(B, T, 5, device="cuda")
+    e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    assert e.split()["status"] == "certified"
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), out)
+    pin_x, pin_p = engine.PinnedArray(x.shape), engine.PinnedArray(out.shape)
+    pin_x.array[...] = x
+    assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), out)
+    cls, pmax = e.forward_decoded_host(x)
+    assert np.array_equal(cls, out.argmax(-1)) and np.array_equal(pmax, out.max(-1))
+    e.close()
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+@pytest.mark.parametrize("B,T", [(1, 10000), (10, 10000), (37, 9999), (100, 10000), (128, 4096), (341, 3072), (3, 3073)])
+def test_split_shapes_vs_sequential(gold, B, T, half):
+    """Reference batch sizes (1 = the un-chunked remainders, 10, 100), odd T, the largest batch that still splits."""
+    x = synth.counts_windows(B, T, depth=40, seed=7 * B + T)
+    e = engine.GruEngine(gold["weights_trained"])
+    e.set_precision(half)
+    out = e.forward_host(x)
+    info = e.split()
+    seq = _sequential(e, x)
+    if info["status"] == "rejected":
+        # half precision, trained weights: junction noise is close to the half-mode threshold (2^-12); a rejected
+        # call returns the sequential bits
+        assert half and np.array_equal(out, seq), info
+    else:
+        assert info["status"] == "certified" and info["chunks"] >= 3, info
+        d = float(np.abs(out - seq).max())
+        assert d <= (2e-4 if half else 2e-6), (info, d)
+        if not half:
+            _check(out, oracle.c_gru_forward(x, gold["weights_trained"]) if B * T <= 400000 else seq, what=str(info))
+    e.close()
+
+
+@pytest.mark.parametrize("B,T", [(8, 2000), (400, 4096), (2, 2047), (30, 256)])
+def test_shapes_outside_the_envelope_are_not_split(gold, B, T):
+    e = engine.GruEngine(gold["weights_init"])
+    x = synth.counts_windows(B, T, seed=B + T)
+    out = e.forward_host(x)
+    assert e.split()["status"] == "not used" and e.split()["chunks"] == 1
+    assert np.array_equal(out, _sequential(e, x))
+    e.close()
+
+
+@pytest.mark.parametrize("name,scale", [("x3", 3.0), ("x5", 5.0)])
+def test_long_memory_models_are_rejected_and_stay_sequential(gold, name, scale):
+    """Weights x3: the two scans are still 1e-5 apart after 256 columns; x5 never forgets (differences of 2.0).  Both
+    must be caught by the certificate, answered with the sequential scan's bits, and not be tried again."""
+    st = {k: (v * np.float32(scale) if k.startswith("gru.weight") else v) for k, v in gold["weights_init"].items()}
+    x = synth.counts_windows(24, 6000, depth=60, seed=5)
+    e = engine.GruEngine(st)
+    out = e.forward_host(x)
+    info = e.split()
+    assert info["status"] == "rejected" and info["fallbacks"] == 1 and info["max_delta"] > 1.9e-6, info
+    again = e.forward_host(x)
+    assert e.split()["status"] == "disabled" and e.split()["fallbacks"] == 1
+    e.set_option("scan_split", 0)
+    assert np.array_equal(out, e.forward_host(x)) and np.array_equal(again, out)
+    # forcing a chunk count keeps trying (and keeps being rejected); a wider margin certifies x3
+    e.set_option("scan_split", 4)
+    assert np.array_equal(e.forward_host(x), out) and e.split()["status"] == "rejected"
+    if name == "x3":
+        e.set_option("scan_split_margin", 744)
+        wide = e.forward_host(x)
+        assert e.split()["status"] == "certified" and e.split()["margin"] == 744 and e.split()["chunks"] == 2, e.split()
+        assert np.abs(wide - out).max() <= 2e-6
+    e.close()
+
+
+def test_margin_and_chunk_options(gold):
+    e = engine.GruEngine(gold["weights_init"])
+    x = synth.counts_windows(16, 8192, seed=3)
+    seq = _sequential(e, x)
+    for chunks, margin in ((2, 256), (3, 128), (8, 64), (16, 32), (5, 1024)):
+        e.set_option("scan_split", chunks)
+        e.set_option("scan_split_margin", margin)
+        out = e.forward_host(x)
+        info = e.split()
+        assert info["chunks"] == min(chunks, 8192 // (4 * margin)) and info["margin"] == margin, info
+        assert info["status"] in ("certified", "rejected")
+        assert np.abs(out - seq).max() <= 2e-6, info          # (rejected: identical)
+    with pytest.raises(Exception):
+        e.set_option("scan_split", 17)
+    with pytest.raises(Exception):
+        e.set_option("scan_split_margin", 100)
+    e.close()
+
+
+def test_sharing_processes_split_less(gold):
+    """`gpu_share` K (launch.py --procs-per-gpu): a process plans for its share of the chip -- 1024 / K virtual windows."""
+    x = synth.counts_windows(100, 4096, seed=9)
+    e = engine.GruEngine(gold["weights_init"])
+    e.forward_host(x)
+    assert e.split()["chunks"] == 4            # min(1024 / 100, 4096 / 1024)
+    e.set_option("gpu_share", 3)
+    e.forward_host(x)
+    assert e.split()["chunks"] == 3            # 341 / 100
+    e.set_option("gpu_share", 4)
+    e.forward_host(x)
+    assert e.split()["status"] == "not used"   # 256 / 100 = 2 chunks: not worth it
+    e.close()
+
+
+def test_model_api_takes_the_split_path(gold):
+    """`GRUModel.predict_on_batch` (the drop-in boundary): same bits as the engine called directly; MDK_SCAN_SPLIT=0
+    in the environment of the process turns the split off for every model created afterwards."""
+    x = synth.counts_windows(12, 10000, seed=21)
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    m = m.to("cuda").eval()
+    out = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+    assert m.engine().split()["status"] == "certified"
+    e = engine.GruEngine(gold["weights_trained"])
+    assert np.array_equal(e.forward_host(x), out)
+    e.close()
+    os.environ["MDK_SCAN_SPLIT"] = "0"
+    try:
+        e = engine.GruEngine(gold["weights_trained"])
+        seq = e.forward_host(x)
+        assert e.split()["status"] == "not used"
+        e.close()
+    finally:
+        del os.environ["MDK_SCAN_SPLIT"]
+    assert np.abs(seq - out).max() <= 2e-6
+
+
+def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
+    """Regression (found by the split scan's certificate): in half-precision mode 16-window work-groups of a batch
+    with an odd number of 8-window tiles ran their surplus lanes on a copy of the last window -- with the fused
+    layer-0 input those lanes see zero rows, and their stores raced with the real ones."""
+    x = synth.counts_windows(24, 900, seed=33)
+    outs = []
+    for tw in (4, 16):
+        e = engine.GruEngine(gold["weights_trained"])
+        e.set_precision(True)
+        e.set_option("rec_windows_per_tile", tw)
+        outs.append(e.forward_host(x))
+        e.close()
+    assert np.array_equal(outs[0], outs[1])
