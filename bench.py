@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
     ap.add_argument("--deferred-store", type=int, default=None, help="recurrence: store h_t from inside step t+1")
+    ap.add_argument("--scan-split", type=int, default=None,
+                    help="split scan (include/medaka_amd.h \"scan_split\"): default = the engine's (1, auto); 0 = the sequential scan "
+                         "only; n >= 2 = force n chunks per window")
+    ap.add_argument("--scan-split-margin", type=int, default=None, help="warm-up columns on either side of a chunk (default 256)")
     ap.add_argument("--model", default="gru", choices=["gru", "rl128", "rl384"],
                     help="gru: the headline consensus model; rl128 / rl384: read-level models (BASELINE config 4b)")
     ap.add_argument("--rl-depth", type=int, default=50, help="read-level models: reads per window")
@@ -517,6 +521,10 @@ def main():
     eng.set_option("overlap_gemm", args.overlap)
     if args.deferred_store is not None:
         eng.set_option("deferred_store", args.deferred_store)
+    if args.scan_split is not None:
+        eng.set_option("scan_split", args.scan_split)
+    if args.scan_split_margin is not None:
+        eng.set_option("scan_split_margin", args.scan_split_margin)
     eng.enable_timing(True)
 
     out_holder = {}
@@ -544,12 +552,22 @@ def main():
     rec_ms = rec_ms[-args.steps * n_layers:]
     cols_per_step = B * T
     value = ranks.world * cols_per_step * args.steps / elapsed
+    split = eng.split()                     # what the timed steps did: chunks per window, certificate
+    sequential = None
+    if split["chunks"] > 1 and not args.device_only:
+        # the same steps as the plain sequential scan, for the record (not `value`): 3 steps after 1 warm-up
+        eng.set_option("scan_split", 0)
+        seq_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
+        eng.set_option("scan_split", args.scan_split if args.scan_split is not None else 1)
+        sequential = {"value": ranks.world * cols_per_step * 3 / seq_elapsed, "unit": "pileup columns/s",
+                      "ms_per_step": 1e3 * seq_elapsed / 3, "steps": 3}
 
     if args.device_only:
         if ranks.rank == 0:
             print(json.dumps({"metric": "pileup columns/sec (consensus bi-GRU inference)", "value": value,
                               "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
                               "ms_per_step": 1e3 * elapsed / args.steps, "device_only": True, "batch_windows": B,
+                              "scan_split": split, "sequential": sequential,
                               "rec_ms_per_step": sum(rec_ms) / args.steps,
                               "gi_ms_per_step": statistics.mean(gi_ms[-args.steps:]),
                               "head_ms_per_step": statistics.mean(head_ms[-args.steps:])}), flush=True)
@@ -600,14 +618,20 @@ def main():
                               "published model archives are git-LFS stubs offline)",
                    "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"
                                   + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
+        "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
+                           f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
+                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-19; 2^-12 in half precision)"
+                           if split["chunks"] > 1 else "sequential scan"),
+        "sequential_scan": sequential,
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
             "ms_per_batch_median": 1e3 * h_med, "timed_batches": len(h2h), "warmup": 2,
             "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
             "input": "page-locked (engine collate)" if args.pinned_input else "pageable (reference collate)",
             "what": "model.predict_on_batch(Batch(counts_matrix=<CPU tensor>)) -> CPU tensor, per rank, "
-                    "median over the timed batches, max over ranks; x streams in and probabilities stream out in "
-                    "time slabs under the recurrences (include/medaka_amd.h: mdk_gru_forward)",
+                    "median over the timed batches, max over ranks; sequential scan: x streams in and probabilities stream "
+                    "out in time slabs under the recurrences; split scan: one copy each way around the device-resident "
+                    "forward (include/medaka_amd.h: mdk_gru_forward)",
             "unstreamed_ms_per_batch": 1e3 * statistics.median(plain),
         },
     }
@@ -647,7 +671,8 @@ def main():
                       "kernel, whose rocprof durations add up to this span)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
-            "pmc": pmc_summary(100, rec_avg_ms, traffic) if (B == 200 and T == 10000 and not args.half) else None,
+            "pmc": pmc_summary(250 if split["chunks"] > 1 else 100, rec_avg_ms, traffic)
+                   if (B == 200 and T == 10000 and not args.half) else None,
             "avg_launch_ms": rec_avg_ms, "launches_timed": len(rec_ms),
             "kernel_launches_per_step": eng.timing()["rec_launches"],
             "algorithmic_flop_per_launch": rec_flop,

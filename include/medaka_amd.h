@@ -71,15 +71,16 @@ typedef struct {
 /* What the last forward did about splitting the scan (option "scan_split" below). */
 #define MDK_SPLIT_NOT_USED 0   /* shape not latency-bound, option off, or model outside the split path */
 #define MDK_SPLIT_CERTIFIED 1  /* ran as `chunks` chunks per window; every junction certified */
-#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-12): the call was repeated sequentially */
+#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-12) at every margin tried:
+                                  the call was answered by the sequential scan */
 #define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected: this model runs sequentially (auto mode) */
 typedef struct {
     int chunks;       /* chunks per window of the last forward (1 = sequential scan) */
-    int margin;       /* warm-up columns on either side of a chunk */
+    int margin;       /* warm-up columns on either side of a chunk (the margin the model has escalated to) */
     int columns;      /* columns of one virtual window (T when not split) */
     int status;       /* MDK_SPLIT_* */
     float max_delta;  /* largest |h_warm - h_carried| over all certificate points of the last split forward */
-    int fallbacks;    /* rejected certificates since the model was created */
+    int fallbacks;    /* rejected certificates since the model was created (each cost one repeated forward) */
 } mdk_gru_split;
 
 /*
@@ -133,16 +134,23 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "deferred_store"       = 1 | 0                  recurrence: h_t leaves for HBM from inside step t+1 (default 1)
  *   "gpu_share"            = 1 .. 8                 processes sharing this GPU (medaka_amd.launch --procs-per-gpu):
  *                                                   work-group sizes are chosen so that all of them fit the chip
- *   "scan_split"           = 1 (auto) | 0 | 2..16      split the scan: batches that leave most of the GPU idle (3 <= chunks <= 1024 / gpu_share / B) run as `chunks` chunks per window, each warmed up over
+ *   "scan_split"           = 1 (auto) | 0 | 2..16   split the scan.  A batch that leaves most of the GPU idle
+ *                                                   (chunks = min(1024 / gpu_share / B, T / (4 * margin)) >= 3, or 2 when T
+ *                                                   is the limit) runs as `chunks` chunks per window, each warmed up over
  *                                                   "scan_split_margin" columns on either side, as ONE batch of
- *                                                   B * chunks windows of about T / chunks + 2 * margin columns; the
+ *                                                   B * chunks windows of about T / chunks + 2 * margin columns.  The
  *                                                   states at every junction are compared on the device (both layers,
- *                                                   both directions, at the junction and margin / 2 columns past it) and
- *                                                   the call is repeated as the sequential scan -- and, in auto mode,
- *                                                   the model stays sequential -- if any differs by more than 2^-19 (2^-12 in half-precision mode).
- *                                                   n >= 2 forces n chunks (bidirectional 2-layer models, T >= 8 * margin)
- *   "scan_split_margin"    = 256 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read when
- *                                                   a model is created, set the defaults of these two options)
+ *                                                   both directions, at the junction and margin / 2 columns past it);
+ *                                                   if any differs by more than 2^-19 (2^-12 in half-precision mode)
+ *                                                   the call is repeated with twice the margin -- kept for later
+ *                                                   calls -- and beyond a margin of 512 as the sequential scan, which
+ *                                                   the model then stays on.  n >= 2 forces n chunks (no escalation:
+ *                                                   a rejected call is answered by the sequential scan).
+ *                                                   Bidirectional 2-layer models, T >= 8 * margin.  Results agree with
+ *                                                   the sequential scan to ~1e-7 (not bit for bit) and depend, at that
+ *                                                   level, on B and on the margin the model has escalated to.
+ *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
+ *                                                   when a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
  *                                                   under the recurrences (0: one copy before, one after)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;

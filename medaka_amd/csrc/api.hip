@@ -90,11 +90,12 @@ struct mdk_gru {
     int opt_stream_host = 1;                 // host path: x in / probabilities out in time slabs under the recurrences
     // split scan (scan_split.hpp)
     int opt_scan_split = 1;                  // 0 off, 1 auto, n >= 2: n chunks per window whenever the shape allows it
-    int opt_split_margin = 256;              // G: columns of warm-up on either side of a chunk
+    int opt_split_margin = 128;              // G: columns of warm-up on either side of a chunk (where the model starts)
+    int split_margin_cur = 0;                // margin in use: doubled (up to kSplitMarginMax) each time a certificate is rejected
     bool split_disabled = false;             // a certificate failed: this model stays sequential (auto mode)
-    float *xv = nullptr, *pv = nullptr;      // virtual batch in, its probabilities out
-    size_t xv_cap = 0, pv_cap = 0;
-    unsigned *split_flag = nullptr;          // device: [0] certificate failed, [1] bits of the largest junction difference
+    float *xv = nullptr;                     // the virtual batch
+    size_t xv_cap = 0;
+    unsigned *split_flag = nullptr;          // device: bits of the largest junction difference per certificate point
     unsigned *split_host = nullptr;          // page-locked copy of split_flag
     mdk_gru_split last_split{};
     // timing
@@ -113,7 +114,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
-    free_dev(m->xv); free_dev(m->pv); free_dev(m->split_flag);
+    free_dev(m->xv); free_dev(m->split_flag);
     if (m->split_host) (void)hipHostFree(m->split_host);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
@@ -341,6 +342,8 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
+        m->split_margin_cur = 0;
+        m->split_disabled = false;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -446,8 +449,10 @@ static int pool_event(mdk_gru *m, hipEvent_t *out) {
     return MDK_OK;
 }
 
+// `sp` (split scan): x holds the virtual batch (nb = sp->S * sp->B windows of T = sp->Tv columns) and `probs` is the
+// REAL (sp->B, sp->T, C) result, filled by the head with every chunk's own columns
 static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs, hipStream_t s,
-                        EvTimer &tm, const HostIO *io) {
+                        EvTimer &tm, const HostIO *io, const SplitPlan *sp = nullptr) {
     const int D = m->D, L = m->desc.num_layers;
     const long M = (long)nb * T;
     const int reverse_mask = (D == 2) ? 2 : 0;
@@ -537,12 +542,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         if (nt <= 0) return;
         const long n_blocks = (long)n_tiles * nt;
         const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
-        if (D == 2)
+        if (sp)       // (plan_split: bidirectional models only)
+            hipLaunchKernelGGL((k_head_tiled<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, src, m->lin_w, m->lin_b,
+                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt, *sp);
+        else if (D == 2)
             hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, st, src, m->lin_w, m->lin_b,
-                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt);
+                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt, SplitPlan{});
         else
             hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, st, src, m->lin_w, m->lin_b,
-                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt);
+                               probs, nb, T, n_tiles, m->desc.normalise, t0, nt, SplitPlan{});
     };
     bool head_done = false;
     // Overlap plan (bidirectional, >= 2 layers): gi of layer 1 at column t needs layer 0's forward h_t
@@ -867,7 +875,7 @@ static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     if (m->opt_scan_split == 0 || (m->split_disabled && m->opt_scan_split == 1)) return false;
     if (m->variant != MDK_VARIANT_MFMA || m->D != 2 || m->desc.num_layers != 2 || m->opt_ablate || env_abl) return false;
     if (m->layers[0].K > 16) return false;
-    const int G = m->opt_split_margin;
+    const int G = m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin;
     // the recurrence holds 8 windows per work-group and direction at most (fp32-parity mode): 1024 virtual windows
     // are one round of work-groups on 256 CUs -- more than that queues (profiles/r3_experiments/scan_split/time_probe.txt)
     const int max_win = 1024 / m->opt_gpu_share;
@@ -897,11 +905,6 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
         HIP_TRY(hipMalloc((void **)&m->xv, cols * F * sizeof(float)));
         m->xv_cap = cols * F;
     }
-    if (cols * C > m->pv_cap) {
-        free_dev(m->pv); m->pv = nullptr; m->pv_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m->pv, cols * C * sizeof(float)));
-        m->pv_cap = cols * C;
-    }
     if (!m->split_flag) {
         HIP_TRY(hipMalloc((void **)&m->split_flag, kSplitFlagWords * sizeof(unsigned)));
         HIP_TRY(hipHostMalloc((void **)&m->split_host, kSplitFlagWords * sizeof(unsigned), hipHostMallocDefault));
@@ -921,32 +924,31 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
                            x_dev, m->xv, sp, (int)F, vec);
     }
     EvTimer tm{m, s};
-    rc = forward_pass(m, m->xv, Bv, sp.Tv, m->pv, s, tm, nullptr);
+    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, nullptr, &sp);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_split_verify, dim3((unsigned)sp.B, (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
-                       (const float *)m->act[0], (const float *)m->act[1], sp,
-                       m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps, m->split_flag);
+    hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
+                       (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);
     HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    {   // the device-resident result (mdk_gru_forward_dev; the host entries that decode on the device read it too)
-        const size_t n = (size_t)sp.B * sp.T * C;
-        hipLaunchKernelGGL(k_split_scatter, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
-                           (const float *)m->pv, probs_dev, sp, (int)C);
-    }
     HIP_TRY(hipGetLastError());
     if (probs_host)
         HIP_TRY(hipMemcpyAsync(probs_host, probs_dev, (size_t)sp.B * sp.T * C * sizeof(float), hipMemcpyDeviceToHost, s));
     if ((rc = finish_timing(m, tm, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
-    float worst;
-    memcpy(&worst, &m->split_host[1], sizeof(float));
-    *certified = m->split_host[0] == 0;
+    const float eps = m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps;
+    float worst = 0.f;
+    for (int y = 0; y < 8 * (sp.S - 1); ++y) {
+        float d;
+        memcpy(&d, &m->split_host[y], sizeof(float));
+        worst = std::max(worst, d);
+    }
+    *certified = worst <= eps;
     static const bool dbg = getenv("MDK_SPLIT_DEBUG") != nullptr;
     if (dbg) {
         fprintf(stderr, "[mdk split] %d x %d as %d chunks of %d columns (margin %d): %s, worst %.3g\n", sp.B, sp.T, sp.S, sp.Tv, sp.G,
                 *certified ? "certified" : "REJECTED", worst);
         for (int y = 0; y < 8 * (sp.S - 1); ++y) {
             float d;
-            memcpy(&d, &m->split_host[2 + y], sizeof(float));
+            memcpy(&d, &m->split_host[y], sizeof(float));
             fprintf(stderr, "    junction %d (column %d) layer %d direction %d point %d: %.3g\n", y >> 3, sp.core0[(y >> 3) + 1], (y >> 2) & 1,
                     (y >> 1) & 1, y & 1, d);
         }
@@ -963,16 +965,23 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
     SplitPlan sp;
     m->last_split.chunks = 1; m->last_split.margin = 0; m->last_split.columns = T; m->last_split.max_delta = 0.f;
     m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
-    if (plan_split(m, B, T, sp)) {
+    static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug: deliver a rejected split as it is
+    while (plan_split(m, B, T, sp)) {
         bool ok = false;
         int rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
         if (rc) return rc;
-        static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug: deliver a rejected split as it is
         if (ok || keep) return MDK_OK;
-        // some junction did not merge (a model with a long or chaotic memory): the sequential scan decides, for this
-        // call and -- in auto mode -- for every later one
+        // Some junction did not merge: this model remembers further back than the margin.  Auto mode tries again with
+        // twice the margin -- and keeps it for later calls -- while the shape still splits and the margin is at most
+        // kSplitMarginMax; after that (a model with a very long or chaotic memory) the sequential scan decides, for this
+        // call and for every later one.  A forced chunk count is not second-guessed: the call is answered sequentially.
         m->last_split.fallbacks++;
-        if (m->opt_scan_split == 1) m->split_disabled = true;
+        if (m->opt_scan_split != 1) break;
+        const int next = 2 * sp.G;
+        if (next > kSplitMarginMax) { m->split_disabled = true; break; }
+        m->split_margin_cur = next;
+        SplitPlan probe;
+        if (!plan_split(m, B, T, probe)) { m->split_disabled = true; break; }   // (this shape no longer splits at that margin)
     }
     return run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
 }

@@ -86,14 +86,18 @@ __global__ __launch_bounds__(256) void k_linear_softmax(
 // the block for i = 0..DIN*4-1: it always sees window (g, q) = ((l>>2)&3, (l>>4)&1) and features
 // 16*(2i + (l>>5)) + 4*(l&3) .. +3; the 8 lanes of a window are xor-reduced (masks 1, 2, 32).
 // Probabilities go out in the reference's natural (B, T, 5) order.
-template <int DIN>
+// SPLIT (split scan, scan_split.hpp): the B windows are virtual ones -- chunk k = win / sp.B of real window win % sp.B,
+// column t = real column sp.start[k] + t; only a chunk's own columns [core0[k], core0[k+1]) are computed and they go
+// straight to their place in the real (sp.B, sp.T, 5) result.
+template <int DIN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_head_tiled(
     const float *__restrict__ act,    // act_t of the last layer
     const float *__restrict__ lin_w,  // [5][DIN*128]
     const float *__restrict__ lin_b,  // [5]
     float *__restrict__ probs,        // [B][T][5]
     int B, int T, int n_tiles, int normalise,
-    int t0, int nt)                   // columns [t0, t0 + nt) of every window
+    int t0, int nt,                   // columns [t0, t0 + nt) of every window
+    SplitPlan sp)
 {
     constexpr int F = DIN * 128;
     __shared__ __attribute__((aligned(16))) float wl[5 * F];
@@ -109,6 +113,15 @@ __global__ __launch_bounds__(256) void k_head_tiled(
     const long n_waves = (long)gridDim.x * (blockDim.x >> 6);
     for (long blk = wave_global; blk < n_blocks; blk += n_waves) {
         const int tile = (int)(blk / nt), t = t0 + (int)(blk % nt);
+        const int win = tile * kTileWin + 2 * g + q;
+        float *dst = probs + ((size_t)win * T + t) * 5;
+        bool deliver = win < B;
+        if constexpr (SPLIT) {
+            const int k = win / sp.B, tr = sp.start[min(k, sp.S - 1)] + t;
+            deliver = deliver && tr >= sp.core0[min(k, sp.S - 1)] && tr < sp.core0[min(k, sp.S - 1) + 1];
+            dst = probs + ((size_t)(win - k * sp.B) * sp.T + tr) * 5;
+            if (!__any(deliver)) continue;        // a margin column of all 8 windows
+        }
         const float *src = act + ((size_t)tile * T + t) * (DIN * 1024) + 4 * lane;
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -131,8 +144,7 @@ __global__ __launch_bounds__(256) void k_head_tiled(
             acc[cl] += __shfl_xor(acc[cl], 32);
             acc[cl] += bv[cl];
         }
-        const int win = tile * kTileWin + 2 * g + q;
-        if (c4 == 0 && hi == 0 && win < B) {
+        if (c4 == 0 && hi == 0 && deliver) {
             float res[5];
             if (normalise) {
                 float mx = acc[0];
@@ -147,7 +159,6 @@ __global__ __launch_bounds__(256) void k_head_tiled(
 #pragma unroll
                 for (int cl = 0; cl < 5; ++cl) res[cl] = acc[cl];
             }
-            float *dst = probs + ((size_t)win * T + t) * 5;
 #pragma unroll
             for (int cl = 0; cl < 5; ++cl) dst[cl] = res[cl];
         }

@@ -36,4 +36,15 @@ __host__ __device__ inline int act_in_block(int dir, int w8, int q, int lane) {
     return ((dir * 8 + w8) * 2 + q) * 64 + lane;
 }
 
+// Split scan (scan_split.hpp): a batch of B windows of T columns runs as S*B virtual windows of Tv columns.
+constexpr int kMaxSplit = 16;
+struct SplitPlan {
+    int S = 1;                    // chunks per window (1 = not split)
+    int B = 0, T = 0;             // the real batch
+    int Tv = 0;                   // columns of a virtual window
+    int G = 0;                    // margin
+    int start[kMaxSplit];         // first real column of chunk k
+    int core0[kMaxSplit + 1];     // real columns [core0[k], core0[k+1]) are delivered from chunk k
+};
+
 }  // namespace mdk

@@ -728,10 +728,10 @@ static int rl_forward_dev_inner(mdk_rl *m, const unsigned char *x_dev, int B, in
         const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
         if (din == 2)
             hipLaunchKernelGGL(k_head_tiled<2>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
-                               probs_dev, B, T, n_tiles, m->desc.normalise, 0, T);
+                               probs_dev, B, T, n_tiles, m->desc.normalise, 0, T, SplitPlan{});
         else
             hipLaunchKernelGGL(k_head_tiled<1>, dim3((unsigned)blocks), dim3(256), 0, s, in, m->lin_w, m->lin_b,
-                               probs_dev, B, T, n_tiles, m->desc.normalise, 0, T);
+                               probs_dev, B, T, n_tiles, m->desc.normalise, 0, T, SplitPlan{});
     }
     HIP_TRY(hipGetLastError());
     return MDK_OK;
