@@ -313,13 +313,13 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
 RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
 
 
-def pmc_summary(n_cus_in_use, rec_avg_ms, traffic_bytes):
+def pmc_summary(n_cus_in_use, rec_avg_ms, traffic_bytes, name="r3_pmc_step.csv"):
     """What north_star asks beside the roofline fraction: matrix-pipe busy share and HBM GB/s of the dominant kernel,
     from the committed counter summary of THIS build at 200 x 10000 (profiles/r3_pmc_step.csv: rocprofv3 --pmc passes of
     `bench.py --device-only --steps 1`, summed over the step by profiles/pmc_step.py) and this run's launch time.
     SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r3_pmc_step.csv")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         busy = active = 0.0
         for row in csv.DictReader(open(path)):
@@ -331,7 +331,7 @@ def pmc_summary(n_cus_in_use, rec_avg_ms, traffic_bytes):
                     active += float(row["sum_over_step"]) / 8.0
         if not busy or not active:
             return None
-        out = {"source": "profiles/r3_pmc_step.csv (B=200, T=10000, this build)",
+        out = {"source": f"profiles/{name} (B=200, T=10000, " + ("split scan, 1000 virtual windows" if name == "r3_pmc_step.csv" else "sequential scan") + ")",
                "mfma_busy_pct_of_chip": 100.0 * busy / (active * 1024),
                "mfma_busy_pct_on_cus_in_use": 100.0 * busy / (active * 4 * n_cus_in_use), "cus_in_use": n_cus_in_use}
         if traffic_bytes:
@@ -654,7 +654,12 @@ def main():
         rec_flop = REC_FLOP_PER_COLUMN_LAYER * cols_per_step
         achieved = rec_flop / (rec_avg_ms * 1e-3) / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        seq_traffic = None
+        try:
+            seq_traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_seq_traffic.json"))).get("k_rec_mfma_bytes_per_launch")
+        except Exception:
+            pass
+        tpath = os.path.join(ROOT, "profiles", "traffic.json" if split["chunks"] > 1 else "r3_seq_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("k_rec_mfma_bytes_per_launch")
@@ -666,12 +671,13 @@ def main():
         issue_factor = 1 if args.half else 4
         peak = PEAK_F16_DENSE_TFLOPS / issue_factor
         result["roofline"] = {
-            "kernel": "k_rec_mfma (GRU recurrence; figures are per LAYER PASS = all windows, both directions, T steps; "
-                      "with the layer-1 projection overlapped, layer 0's pass is 7 resumable launches of the same "
-                      "kernel, whose rocprof durations add up to this span)",
+            "kernel": "k_rec_mfma (GRU recurrence; figures are per LAYER PASS = all windows, both directions, every step; "
+                      "layer 0's pass is several resumable launches of the same kernel, whose rocprof durations add up to "
+                      "this span; the algorithmic FLOP are those of the REAL columns -- the margins a split scan adds are overhead)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
-            "pmc": pmc_summary(250 if split["chunks"] > 1 else 100, rec_avg_ms, traffic)
+            "pmc": (pmc_summary(250, rec_avg_ms, traffic) if split["chunks"] > 1 else
+                    pmc_summary(100, rec_avg_ms, seq_traffic, "r3_seq_pmc_step.csv"))
                    if (B == 200 and T == 10000 and not args.half) else None,
             "avg_launch_ms": rec_avg_ms, "launches_timed": len(rec_ms),
             "kernel_launches_per_step": eng.timing()["rec_launches"],

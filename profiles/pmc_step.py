@@ -62,8 +62,9 @@ def main():
                 fams[fam] = {"FETCH_SIZE_KB_sum": acc[fam].get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB_sum": acc[fam].get("WRITE_SIZE", 0.0),
                              "hbm_bytes_per_step": b, "algorithmic_bytes_per_step": algo.get(fam)}
                 total += b
-        rec = [v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_mfma<NQ=1") and "twin" not in k]
-        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward, overlap on; rocprofv3 --pmc FETCH_SIZE / "
+        # one entry per layer pass (fused layer 0, layer 1), whatever work-group size the step ran with
+        rec = [v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_mfma<") and "twin" not in k]
+        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward at the engine's defaults (split scan: 5 chunks per window, margin 128 -> 1000 virtual windows of 2256 columns; profiles/r3_seq_traffic.json = the sequential scan); rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE in separate passes, summed over every dispatch of the step per kernel family; "
                              "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
                    "families": fams, "total_hbm_bytes_per_step": total,
