@@ -166,14 +166,22 @@ __global__ __launch_bounds__(512, MT <= 4 ? 4 : 2) void k_gi_gemm(
             for (int nt = 0; nt < NG; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * KSTEPS) * (2 * NG) * 64 + lane;
-#pragma unroll 1
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            half8 bh[NG], bl[NG];
+        // W_ih B-fragments come from L2 (all work-groups stream the same 786 KB): the fragments of k-step ks + 1 are
+        // requested before the 36 MFMAs of k-step ks are issued (two register sets, the loop runs two k-steps per
+        // trip so that the set index is static; 60 -> 122 VGPRs, still four waves per SIMD) -- before, every k-step
+        // began by waiting one L2 round trip.  Bit-identical; measured -4 % at 1000 x 2256 (the split scan's shape,
+        // 2.73 -> 2.63 ms) and nothing at 1000 x 10000: the other work-group of the CU was already covering most of
+        // that wait, and the kernel sits on L2 (10.5 TB/s of fragment reads), HBM (3.8 TB/s) and a 57 % busy,
+        // power-limited matrix pipe at once.
+        half8 bh[2][NG], bl[2][NG];
+        auto load_b = [&](int ks, int set) {
 #pragma unroll
             for (int nt = 0; nt < NG; ++nt) {
-                bh[nt] = wp[(size_t)((ks * NG + nt) * 2 + 0) * 64];
-                if constexpr (!HP) bl[nt] = wp[(size_t)((ks * NG + nt) * 2 + 1) * 64];
+                bh[set][nt] = wp[(size_t)((ks * NG + nt) * 2 + 0) * 64];
+                if constexpr (!HP) bl[set][nt] = wp[(size_t)((ks * NG + nt) * 2 + 1) * 64];
             }
+        };
+        auto kstep = [&](int ks, int set) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
@@ -181,13 +189,26 @@ __global__ __launch_bounds__(512, MT <= 4 ? 4 : 2) void k_gi_gemm(
                 if constexpr (!HP) al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                 for (int nt = 0; nt < NG; ++nt) {
-                    acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
+                    acc[mt][nt] = mfma16(ah, bh[set][nt], acc[mt][nt]);
                     if constexpr (!HP) {
-                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(al, bh[set][nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bl[set][nt], acc[mt][nt]);
                     }
                 }
             }
+        };
+        static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
+        load_b(0, 0);
+#pragma unroll 1
+        for (int ks = 0; ks < KSTEPS; ks += 2) {
+            load_b(ks + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the requests to the end of the trip)
+            kstep(ks, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < KSTEPS) load_b(ks + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(ks + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue: scale back, add folded bias, 256-byte runs per accumulator register

@@ -261,3 +261,16 @@ def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
         outs.append(e.forward_host(x))
         e.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_out_of_range_input_inside_a_split_call(gold):
+    """Un-normalised counts raise the fp16 range flag of the fused layer-0 input (k_pack_x): the unfused fp32 projection
+    and its recurrence twin take over ON THE DEVICE -- also when the forward is a split one."""
+    x = synth.counts_windows(5, 2048, seed=43) * np.float32(3000.0)
+    for wname in ("x3", "trained"):
+        e = engine.GruEngine(weight_set(gold, wname))
+        out = e.forward_host(x)
+        info = e.split()
+        assert info["status"] in ("certified", "rejected") and info["fallbacks"] <= 3, info
+        _check(out, oracle.c_gru_forward(x, weight_set(gold, wname)), what=f"{wname} out-of-range input, {info}")
+        e.close()
