@@ -135,8 +135,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "gpu_share"            = 1 .. 8                 processes sharing this GPU (medaka_amd.launch --procs-per-gpu):
  *                                                   work-group sizes are chosen so that all of them fit the chip
  *   "scan_split"           = 1 (auto) | 0 | 2..16   split the scan.  A batch that leaves most of the GPU idle
- *                                                   (chunks = min(1024 / gpu_share / B, T / (4 * margin)) >= 3, or 2 when T
- *                                                   is the limit) runs as `chunks` chunks per window, each warmed up over
+ *                                                   (chunks = min(W / B, T / (4 * margin)) >= 3 -- or 2 when T is the limit or
+ *                                                   the GPU is shared -- with W = 1024 chunk-windows, 1600 / gpu_share
+ *                                                   for a process that shares the GPU) runs as `chunks` chunks per window, each warmed up over
  *                                                   "scan_split_margin" columns on either side, as ONE batch of
  *                                                   B * chunks windows of about T / chunks + 2 * margin columns.  The
  *                                                   states at every junction are compared on the device (both layers,

@@ -878,9 +878,14 @@ static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     const int G = m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin;
     // the recurrence holds 8 windows per work-group and direction at most (fp32-parity mode): 1024 virtual windows
     // are one round of work-groups on 256 CUs -- more than that queues (profiles/r3_experiments/scan_split/time_probe.txt)
-    const int max_win = 1024 / m->opt_gpu_share;
+    // K processes sharing the GPU (launch.py --procs-per-gpu): their kernels interleave -- one is in its projection
+    // while another is in a recurrence -- and 1600 / K chunk-windows each measured best (profiles/r3_fed_loop_shared.txt:
+    // K = 3 at batch 200, whole fed loop: 249 M columns/s unsplit, 290 M with 2 chunks, 284 M with 3)
+    const int share = m->opt_gpu_share;
+    const int max_win = share == 1 ? 1024 : 1600 / share;
     int S = (m->opt_scan_split >= 2) ? m->opt_scan_split : max_win / std::max(B, 1);
-    if (m->opt_scan_split == 1 && S < 3) return false;   // two chunks of 500 windows: +8 % on the device, nothing host to host
+    // alone, two chunks of 500 windows gain 8 % on the device and nothing host to host: not worth the margins
+    if (m->opt_scan_split == 1 && S < (share == 1 ? 3 : 2)) return false;
     S = std::min({S, kMaxSplit, T / (4 * G)});      // a chunk's own columns are at least twice its two margins
     if (S < 2) return false;
     p.S = S; p.B = B; p.T = T; p.G = G;

@@ -211,17 +211,17 @@ def test_margin_and_chunk_options(gold):
 
 
 def test_sharing_processes_split_less(gold):
-    """`gpu_share` K (launch.py --procs-per-gpu): a process plans for its share of the chip -- 1024 / K virtual windows."""
+    """`gpu_share` K (launch.py --procs-per-gpu): a process plans for its share of the chip -- 1600 / K chunk-windows
+    (the kernels of K processes interleave; profiles/r3_fed_loop_shared.txt) against 1024 when it has the GPU to itself."""
     x = synth.counts_windows(100, 4096, seed=9)
     e = engine.GruEngine(gold["weights_init"])
+    for share, chunks in ((1, 8), (2, 8), (3, 5), (4, 4), (8, 2)):     # min(max_win / 100, 4096 / (4 * 128))
+        e.set_option("gpu_share", share)
+        e.forward_host(x)
+        assert e.split()["chunks"] == chunks and e.split()["status"] == "certified", (share, e.split())
+    x = synth.counts_windows(210, 2048, seed=10)
     e.forward_host(x)
-    assert e.split()["chunks"] == 8            # min(1024 / 100, 4096 / (4 * 128))
-    e.set_option("gpu_share", 3)
-    e.forward_host(x)
-    assert e.split()["chunks"] == 3            # 341 / 100
-    e.set_option("gpu_share", 4)
-    e.forward_host(x)
-    assert e.split()["status"] == "not used"   # 256 / 100 = 2 chunks: not worth it
+    assert e.split()["status"] == "not used"   # 200 / 210: nothing left to split at K = 8
     e.close()
 
 
