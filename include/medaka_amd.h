@@ -170,6 +170,16 @@ int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);
 /* Chunks, margin and certificate of the last forward (see "scan_split"). */
 int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out);
 
+/* The shape arithmetic of "scan_split" on its own (no device needed): how a batch of B windows of T columns would be
+ * split by a process that is one of `gpu_share` on its GPU, with option values `scan_split` (1 auto, n >= 2 forced) and
+ * `margin`.  chunks = 1: not split.  Chunk k is columns [start[k], start[k] + columns) of every window and delivers
+ * columns [first[k], last[k]); the delivered ranges tile [0, T). */
+typedef struct {
+    int chunks, columns, margin;
+    int start[16], first[16], last[16];
+} mdk_split_shape;
+int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_split_shape *out);
+
 /* Device ordinal the model lives on (`TorchModel.device()`, models.py:291-296). */
 int mdk_gru_device(const mdk_gru *m);
 void mdk_gru_destroy(mdk_gru *m);

@@ -869,33 +869,54 @@ static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs
 }
 
 // ---- split scan (scan_split.hpp): plan, run on the virtual batch, certify, fall back
+// The shape arithmetic of a split, free of any model state (also exported as mdk_split_plan for hosts and CPU tests).
+//   mode: 1 auto, n >= 2 forced chunk count; share: processes on this GPU; G: margin; budget: column budget of a pass
+static bool plan_split_shape(int B, int T, int share, int mode, int G, size_t budget, SplitPlan &p) {
+    p.S = 1; p.B = B; p.T = T; p.Tv = T; p.G = 0;
+    if (B < 1 || T < 1 || mode < 1 || G < 8 || share < 1) return false;
+    // The recurrence holds 8 windows per work-group and direction at most (fp32-parity mode): 1024 chunk-windows are
+    // one round of work-groups on 256 CUs -- more than that queues (profiles/r3_experiments/scan_split/time_probe.txt).
+    // K processes sharing the GPU (launch.py --procs-per-gpu): their kernels interleave -- one is in its projection
+    // while another is in a recurrence -- and 1600 / K chunk-windows each measured best (profiles/r3_fed_loop_shared.txt:
+    // K = 3 at batch 200, whole fed loop: 249 M columns/s unsplit, 290 M with 2 chunks, 284 M with 3)
+    const int max_win = share == 1 ? 1024 : 1600 / share;
+    int S = (mode >= 2) ? mode : max_win / B;
+    // alone, two chunks of 500 windows gain 8 % on the device and nothing host to host: not worth the margins
+    if (mode == 1 && S < (share == 1 ? 3 : 2)) return false;
+    S = std::min({S, kMaxSplit, T / (4 * G)});      // a chunk's own columns are at least twice its two margins
+    if (S < 2) return false;
+    int max_core = 0, core0[kMaxSplit + 1];
+    for (int k = 0; k <= S; ++k) core0[k] = (int)((long)T * k / S);
+    for (int k = 0; k < S; ++k) max_core = std::max(max_core, core0[k + 1] - core0[k]);
+    const int Tv = (max_core + 2 * G + 15) / 16 * 16;
+    if (Tv >= T || (size_t)S * B * Tv > budget) return false;
+    p.S = S; p.G = G; p.Tv = Tv;
+    for (int k = 0; k <= S; ++k) p.core0[k] = core0[k];
+    for (int k = 0; k < S; ++k) p.start[k] = std::min(std::max(core0[k] - G, 0), T - Tv);
+    return true;
+}
+
+extern "C" int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_split_shape *out) {
+    if (!out) return fail(MDK_ERR_ARG, "null argument");
+    if (B < 0 || T < 0 || gpu_share < 1 || gpu_share > 8 || scan_split < 0 || scan_split > kMaxSplit || margin < 16 || margin > 4096 || margin % 8)
+        return fail(MDK_ERR_ARG, "bad argument (B=%d T=%d gpu_share=%d scan_split=%d margin=%d)", B, T, gpu_share, scan_split, margin);
+    SplitPlan p;
+    plan_split_shape(B, T, gpu_share, scan_split, margin, kMaxRowsPerPass, p);
+    memset(out, 0, sizeof(*out));
+    out->chunks = p.S; out->columns = p.S > 1 ? p.Tv : T; out->margin = p.S > 1 ? p.G : 0;
+    for (int k = 0; k < p.S && p.S > 1; ++k) { out->start[k] = p.start[k]; out->first[k] = p.core0[k]; out->last[k] = p.core0[k + 1]; }
+    if (p.S == 1) { out->start[0] = 0; out->first[0] = 0; out->last[0] = T; }
+    return MDK_OK;
+}
+
 static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
     p.S = 1;
     if (m->opt_scan_split == 0 || (m->split_disabled && m->opt_scan_split == 1)) return false;
     if (m->variant != MDK_VARIANT_MFMA || m->D != 2 || m->desc.num_layers != 2 || m->opt_ablate || env_abl) return false;
     if (m->layers[0].K > 16) return false;
-    const int G = m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin;
-    // the recurrence holds 8 windows per work-group and direction at most (fp32-parity mode): 1024 virtual windows
-    // are one round of work-groups on 256 CUs -- more than that queues (profiles/r3_experiments/scan_split/time_probe.txt)
-    // K processes sharing the GPU (launch.py --procs-per-gpu): their kernels interleave -- one is in its projection
-    // while another is in a recurrence -- and 1600 / K chunk-windows each measured best (profiles/r3_fed_loop_shared.txt:
-    // K = 3 at batch 200, whole fed loop: 249 M columns/s unsplit, 290 M with 2 chunks, 284 M with 3)
-    const int share = m->opt_gpu_share;
-    const int max_win = share == 1 ? 1024 : 1600 / share;
-    int S = (m->opt_scan_split >= 2) ? m->opt_scan_split : max_win / std::max(B, 1);
-    // alone, two chunks of 500 windows gain 8 % on the device and nothing host to host: not worth the margins
-    if (m->opt_scan_split == 1 && S < (share == 1 ? 3 : 2)) return false;
-    S = std::min({S, kMaxSplit, T / (4 * G)});      // a chunk's own columns are at least twice its two margins
-    if (S < 2) return false;
-    p.S = S; p.B = B; p.T = T; p.G = G;
-    int max_core = 0;
-    for (int k = 0; k <= S; ++k) p.core0[k] = (int)((long)T * k / S);
-    for (int k = 0; k < S; ++k) max_core = std::max(max_core, p.core0[k + 1] - p.core0[k]);
-    p.Tv = (max_core + 2 * G + 15) / 16 * 16;
-    if (p.Tv >= T || (size_t)S * B * p.Tv > (m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass)) { p.S = 1; return false; }
-    for (int k = 0; k < S; ++k) p.start[k] = std::min(std::max(p.core0[k] - G, 0), T - p.Tv);
-    return true;
+    return plan_split_shape(B, T, m->opt_gpu_share, m->opt_scan_split, m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin,
+                            m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass, p);
 }
 
 static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,

@@ -21,6 +21,17 @@ def state_keys(n_layers=2, bidirectional=True):
     return keys
 
 
+def split_plan(B, T, gpu_share=1, scan_split=1, margin=128):
+    """How the engine would split a batch of B windows of T columns (include/medaka_amd.h `mdk_split_plan`; no device
+    needed): {"chunks", "columns", "margin", "start": [...], "first": [...], "last": [...]}."""
+    t = _lib.SplitShape()
+    _lib.check(_lib.load().mdk_split_plan(int(B), int(T), int(gpu_share), int(scan_split), int(margin), ctypes.byref(t)),
+               "mdk_split_plan")
+    n = t.chunks
+    return {"chunks": n, "columns": t.columns, "margin": t.margin, "start": list(t.start)[:n], "first": list(t.first)[:n],
+            "last": list(t.last)[:n]}
+
+
 class DeviceBuffer:
     """Raw device allocation through the C ABI (for hosts without a HIP binding of their own)."""
 

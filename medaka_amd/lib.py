@@ -44,6 +44,11 @@ class GruSplit(ctypes.Structure):
                 ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int)]
 
 
+class SplitShape(ctypes.Structure):
+    _fields_ = [("chunks", ctypes.c_int), ("columns", ctypes.c_int), ("margin", ctypes.c_int),
+                ("start", ctypes.c_int * 16), ("first", ctypes.c_int * 16), ("last", ctypes.c_int * 16)]
+
+
 SPLIT_STATUS = {0: "not used", 1: "certified", 2: "rejected", 3: "disabled"}
 
 
@@ -61,6 +66,7 @@ ABI = {
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
+    "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),
     "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),
