@@ -544,6 +544,9 @@ def main():
         total_ms.append(t["total_ms"])
 
     log('engine ready, timing')
+    step()                                   # the model's first call: a split scan is audited against the sequential one
+    torch.cuda.synchronize(dev)
+    first_call = eng.split()
     elapsed, mine = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev),
                                      steps=args.steps, warmup=args.warmup)
     log(f'timed region done: {elapsed:.3f}s for {args.steps} steps')
@@ -553,6 +556,8 @@ def main():
     cols_per_step = B * T
     value = ranks.world * cols_per_step * args.steps / elapsed
     split = eng.split()                     # what the timed steps did: chunks per window, certificate
+    split["first_call_audited"] = first_call["audited"]          # (one extra, untimed call before the warm-up steps)
+    split["first_call_audit_max_dp"] = first_call["audit_max_dp"]
     sequential = None
     if split["chunks"] > 1 and not args.device_only:
         # the same steps as the plain sequential scan, for the record (not `value`): 3 steps after 1 warm-up
@@ -620,7 +625,8 @@ def main():
                                   + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
         "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
-                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-19; 2^-12 in half precision)"
+                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-19; 2^-12 in half precision); the model's first call "
+                           "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp)"
                            if split["chunks"] > 1 else "sequential scan"),
         "sequential_scan": sequential,
         "host_to_host": {

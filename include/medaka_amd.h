@@ -81,6 +81,8 @@ typedef struct {
     int status;       /* MDK_SPLIT_* */
     float max_delta;  /* largest |h_warm - h_carried| over all certificate points of the last split forward */
     int fallbacks;    /* rejected certificates since the model was created (each cost one repeated forward) */
+    int audited;      /* 1: this call was also run as the sequential scan and the two results compared in full */
+    float audit_max_dp; /* largest |p_split - p_sequential| of that comparison */
 } mdk_gru_split;
 
 /*
@@ -150,6 +152,11 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   Bidirectional 2-layer models, T >= 8 * margin.  Results agree with
  *                                                   the sequential scan to ~1e-7 (not bit for bit) and depend, at that
  *                                                   level, on B and on the margin the model has escalated to.
+ *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
+ *                                                   it escalates to -- is also run as the sequential scan and the two
+ *                                                   results are compared in full (4e-6; half precision 2e-4); a mismatch
+ *                                                   delivers the sequential result and turns the split off.  One extra
+ *                                                   forward per model.  2: every certified call (debug), 0: never
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs

@@ -98,6 +98,10 @@ struct mdk_gru {
     unsigned *split_flag = nullptr;          // device: bits of the largest junction difference per certificate point
     unsigned *split_host = nullptr;          // page-locked copy of split_flag
     mdk_gru_split last_split{};
+    int opt_split_audit = 1;                 // 0 never, 1 the first certified call of every margin, 2 every certified call
+    int split_audited_margin = 0;            // margin whose first certified call has been audited (0 = none yet)
+    float *audit = nullptr;                  // the sequential scan's probabilities of an audited call
+    size_t audit_cap = 0;
     // timing
     bool timing = false;
     mdk_gru_timing last{};
@@ -114,7 +118,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     }
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
-    free_dev(m->xv); free_dev(m->split_flag);
+    free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
     if (m->split_host) (void)hipHostFree(m->split_host);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
@@ -339,6 +343,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         if (value < 0 || value > kMaxSplit) return fail(MDK_ERR_ARG, "scan_split must be 0 (off), 1 (auto) or 2..%d chunks", kMaxSplit);
         m->opt_scan_split = value;
         m->split_disabled = false;           // setting the option re-arms a model that fell back
+    } else if (!strcmp(key, "scan_split_audit")) {
+        if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
+        m->opt_split_audit = value;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
@@ -990,13 +997,51 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
                        const float *x_host, float *probs_host) {
     SplitPlan sp;
     m->last_split.chunks = 1; m->last_split.margin = 0; m->last_split.columns = T; m->last_split.max_delta = 0.f;
+    m->last_split.audited = 0; m->last_split.audit_max_dp = 0.f;
     m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
     static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug: deliver a rejected split as it is
     while (plan_split(m, B, T, sp)) {
         bool ok = false;
         int rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
         if (rc) return rc;
-        if (ok || keep) return MDK_OK;
+        if (keep) return MDK_OK;
+        if (ok) {
+            // Audit: the first certified call of a model (and the first at every margin it escalates to) is ALSO run as
+            // the sequential scan, and the two results are compared in full -- the certificate argues from the states
+            // at the junctions, the audit looks at what is delivered.  One extra forward per model, not per call.
+            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_margin == sp.G)) return MDK_OK;
+            const size_t n = (size_t)B * T * m->desc.num_classes;
+            if (n > m->audit_cap) {
+                free_dev(m->audit); m->audit = nullptr; m->audit_cap = 0;
+                HIP_TRY(hipMalloc((void **)&m->audit, n * sizeof(float)));
+                m->audit_cap = n;
+            }
+            const mdk_gru_split certified = m->last_split;
+            rc = run_passes(m, x_dev, B, T, m->audit, s, nullptr, nullptr);      // (x_dev holds x also on the host path)
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(m->split_flag, 0, sizeof(unsigned), s));
+            hipLaunchKernelGGL(k_split_audit, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, s,
+                               (const float *)probs_dev, (const float *)m->audit, n, m->split_flag);
+            HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            float dp;
+            memcpy(&dp, &m->split_host[0], sizeof(float));
+            m->last_split = certified;
+            m->last_split.audited = 1;
+            m->last_split.audit_max_dp = dp;
+            if (dp <= (m->precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol)) {
+                m->split_audited_margin = sp.G;
+                return MDK_OK;
+            }
+            // never seen: certified junctions, different probabilities.  The sequential result is already there.
+            m->last_split.status = MDK_SPLIT_REJECTED;
+            m->last_split.fallbacks++;
+            m->split_disabled = true;
+            HIP_TRY(hipMemcpyAsync(probs_dev, m->audit, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (probs_host) HIP_TRY(hipMemcpyAsync(probs_host, m->audit, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            return MDK_OK;
+        }
         // Some junction did not merge: this model remembers further back than the margin.  Auto mode tries again with
         // twice the margin -- and keeps it for later calls -- while the shape still splits and the margin is at most
         // kSplitMarginMax; after that (a model with a very long or chaotic memory) the sequential scan decides, for this

@@ -34,6 +34,10 @@ constexpr int kSplitFlagWords = 8 * (kMaxSplit - 1);   // certificate words on t
 // NOT merged (weights x3: memory longer than the margin) show 1e-5 / 5e-4 and more.
 constexpr float kSplitEps = 1.9073486328125e-06f;     // 2^-19
 constexpr float kSplitEpsHalf = 2.44140625e-04f;      // 2^-12
+// Audit threshold on the probabilities (split result vs the sequential scan of the same call): measured 2.4e-7 (fp32
+// parity) and 1e-6 (half) on certified calls; the contract tolerance is 1e-4.
+constexpr float kAuditTol = 4.0e-6f;
+constexpr float kAuditTolHalf = 2.0e-4f;
 
 // x (B, T, F) -> xv (S*B, Tv, F): rows of Tv*F floats, copied as float2 (every row starts on a multiple of 2*F floats
 // only when F is even: the odd case falls back to scalar copies through `vec` = 1)
@@ -90,6 +94,21 @@ static __global__ __launch_bounds__(128) void k_split_verify(const float *__rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
     if ((threadIdx.x & 63) == 0 && worst > 0.f) atomicMax(&flag[blockIdx.y], __float_as_uint(worst));
+}
+
+// Audit (first certified call of a model, and again whenever its margin has changed): the largest |a - b| over two
+// probability arrays -- the split result against the sequential scan of the same call.  flag[0] = its bit pattern.
+static __global__ __launch_bounds__(256) void k_split_audit(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                            unsigned *__restrict__ flag) {
+    float worst = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float d = fabsf(a[i] - b[i]);
+        if (!(d <= 4.0f)) d = __builtin_inff();
+        worst = fmaxf(worst, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+    if ((threadIdx.x & 63) == 0 && worst > 0.f) atomicMax(&flag[0], __float_as_uint(worst));
 }
 
 }  // namespace mdk

@@ -150,7 +150,7 @@ class GruEngine:
         t = _lib.GruSplit()
         _lib.check(_lib.load().mdk_gru_get_split(self._h, ctypes.byref(t)), "mdk_gru_get_split")
         return {"chunks": t.chunks, "margin": t.margin, "columns": t.columns, "status": _lib.SPLIT_STATUS.get(t.status, t.status),
-                "max_delta": t.max_delta, "fallbacks": t.fallbacks}
+                "max_delta": t.max_delta, "fallbacks": t.fallbacks, "audited": bool(t.audited), "audit_max_dp": t.audit_max_dp}
 
     # -- compute
     def forward_host(self, x, out=None):

@@ -41,7 +41,8 @@ class GruTiming(ctypes.Structure):
 
 class GruSplit(ctypes.Structure):
     _fields_ = [("chunks", ctypes.c_int), ("margin", ctypes.c_int), ("columns", ctypes.c_int),
-                ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int)]
+                ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int),
+                ("audited", ctypes.c_int), ("audit_max_dp", ctypes.c_float)]
 
 
 class SplitShape(ctypes.Structure):

@@ -85,7 +85,13 @@ def test_full_batch_split_vs_oracle_and_sequential(gold):
     info = e.split()
     assert info == {**info, "chunks": 5, "margin": 128, "status": "certified", "fallbacks": 0}, info
     assert info["max_delta"] <= 1.0e-6
+    # the first certified call of a model is audited: run again as the sequential scan on the device, compared in full
+    assert info["audited"] and info["audit_max_dp"] <= 4e-6, info
     assert np.array_equal(e.forward_host(x), out)                         # deterministic
+    assert not e.split()["audited"]                                       # ... once per model (and margin)
+    e.set_option("scan_split_audit", 2)
+    assert np.array_equal(e.forward_host(x), out) and e.split()["audited"] and e.split()["audit_max_dp"] == info["audit_max_dp"]
+    e.set_option("scan_split_audit", 1)
     seq = _sequential(e, x)
     d = float(np.abs(out - seq).max())
     print(f"split (5 chunks, margin 128) vs sequential over {B * T} columns: max|dp| = {d:.2e}, largest junction "
