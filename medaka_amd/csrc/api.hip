@@ -99,7 +99,7 @@ struct mdk_gru {
     unsigned *split_host = nullptr;          // page-locked copy of split_flag
     mdk_gru_split last_split{};
     int opt_split_audit = 1;                 // 0 never, 1 the first certified call of every margin, 2 every certified call
-    int split_audited_margin = 0;            // margin whose first certified call has been audited (0 = none yet)
+    int split_audited_key = 0;               // margin | precision << 16 whose first certified call has been audited (0 = none yet)
     float *audit = nullptr;                  // the sequential scan's probabilities of an audited call
     size_t audit_cap = 0;
     // timing
@@ -1006,10 +1006,11 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         if (rc) return rc;
         if (keep) return MDK_OK;
         if (ok) {
-            // Audit: the first certified call of a model (and the first at every margin it escalates to) is ALSO run as
+            // Audit: the first certified call of a model (and the first at every margin / precision it moves to) is ALSO run as
             // the sequential scan, and the two results are compared in full -- the certificate argues from the states
             // at the junctions, the audit looks at what is delivered.  One extra forward per model, not per call.
-            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_margin == sp.G)) return MDK_OK;
+            const int audit_key = sp.G | (m->precision << 16) | (1 << 24);
+            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_key == audit_key)) return MDK_OK;
             const size_t n = (size_t)B * T * m->desc.num_classes;
             if (n > m->audit_cap) {
                 free_dev(m->audit); m->audit = nullptr; m->audit_cap = 0;
@@ -1030,7 +1031,7 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
             m->last_split.audited = 1;
             m->last_split.audit_max_dp = dp;
             if (dp <= (m->precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol)) {
-                m->split_audited_margin = sp.G;
+                m->split_audited_key = audit_key;
                 return MDK_OK;
             }
             // never seen: certified junctions, different probabilities.  The sequential result is already there.

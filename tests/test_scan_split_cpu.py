@@ -84,3 +84,34 @@ def test_bad_arguments_are_errors():
             engine.split_plan(*args)
     assert engine.split_plan(0, 0)["chunks"] == 1
     assert engine.split_plan(5, 10000, scan_split=0)["chunks"] == 1
+
+
+def test_premise_on_the_reference_arithmetic(gold):
+    """The premise of the split, checked with the reference's own arithmetic (PyTorch-CPU nn.GRU -> Linear -> softmax,
+    oracle.make_torch_oracle) and the engine's own plan: a chunk that starts from h = 0 one margin before its first
+    delivered column, and ends one margin after its last, gives on its delivered columns what the full scan gives
+    there -- to rounding for the bundled architecture's weights, and visibly NOT for a model that does not forget
+    (weights x 5), which is why the engine certifies every junction instead of assuming this."""
+    import numpy as np
+    from medaka_amd import synth
+    from oracle import oracle
+    B, T = 3, 4096
+    x = synth.counts_windows(B, T, depth=50, seed=11)
+    plan = engine.split_plan(B, T, scan_split=4, margin=128)
+    assert plan["chunks"] == 4
+
+    def stitched(model):
+        out = np.empty((B, T, 5), np.float32)
+        for k in range(plan["chunks"]):
+            s, a, b = plan["start"][k], plan["first"][k], plan["last"][k]
+            out[:, a:b] = model.predict(np.ascontiguousarray(x[:, s:s + plan["columns"]])).numpy()[:, a - s:b - s]
+        return out
+
+    for name, scale, bound in (("trained", 1.0, 2e-6), ("init", 1.0, 2e-6), ("init", 5.0, None)):
+        st = {k: (v * np.float32(scale) if k.startswith("gru.weight") else v) for k, v in gold["weights_" + name].items()}
+        model = oracle.make_torch_oracle(st)
+        d = float(np.abs(stitched(model) - model.predict(x).numpy()).max())
+        if bound is not None:
+            assert d <= bound, (name, scale, d)
+        else:
+            assert d > 1e-2, (name, scale, d)
