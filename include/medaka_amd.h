@@ -71,7 +71,7 @@ typedef struct {
 /* What the last forward did about splitting the scan (option "scan_split" below). */
 #define MDK_SPLIT_NOT_USED 0   /* shape not latency-bound, option off, or model outside the split path */
 #define MDK_SPLIT_CERTIFIED 1  /* ran as `chunks` chunks per window; every junction certified */
-#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-12) at every margin tried:
+#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-10) at every margin tried:
                                   the call was answered by the sequential scan */
 #define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected: this model runs sequentially (auto mode) */
 typedef struct {
@@ -144,7 +144,7 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   B * chunks windows of about T / chunks + 2 * margin columns.  The
  *                                                   states at every junction are compared on the device (both layers,
  *                                                   both directions, at the junction and margin / 2 columns past it);
- *                                                   if any differs by more than 2^-19 (2^-12 in half-precision mode)
+ *                                                   if any differs by more than 2^-19 (2^-10 in half-precision mode)
  *                                                   the call is repeated with twice the margin -- kept for later
  *                                                   calls -- and beyond a margin of 512 as the sequential scan, which
  *                                                   the model then stays on.  n >= 2 forces n chunks (no escalation:
@@ -154,7 +154,7 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   level, on B and on the margin the model has escalated to.
  *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
  *                                                   it escalates to -- is also run as the sequential scan and the two
- *                                                   results are compared in full (4e-6; half precision 2e-4); a mismatch
+ *                                                   results are compared in full (4e-6; half precision 4e-4); a mismatch
  *                                                   delivers the sequential result and turns the split off.  One extra
  *                                                   forward per model.  2: every certified call (debug), 0: never
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read

@@ -131,11 +131,7 @@ def test_split_shapes_vs_sequential(gold, B, T, half):
     out = e.forward_host(x)
     info = e.split()
     seq = _sequential(e, x)
-    if info["status"] == "rejected":
-        # half precision, trained weights: junction noise is close to the half-mode threshold (2^-12); a rejected
-        # call returns the sequential bits
-        assert half and np.array_equal(out, seq), info
-    else:
+    if True:
         assert info["status"] == "certified" and info["chunks"] >= 3, info
         d = float(np.abs(out - seq).max())
         assert d <= (2e-4 if half else 2e-6), (info, d)
