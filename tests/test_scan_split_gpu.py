@@ -276,3 +276,28 @@ def test_out_of_range_input_inside_a_split_call(gold):
         assert info["status"] in ("certified", "rejected") and info["fallbacks"] <= 3, info
         _check(out, oracle.c_gru_forward(x, weight_set(gold, wname)), what=f"{wname} out-of-range input, {info}")
         e.close()
+
+
+def test_stitched_fastq_identical_to_reference_with_the_split_scan(gold):
+    """Row a9 at the product default: the engine inside the reference's loop shape and on through trim / stitch gives
+    the UNMODIFIED reference's FASTQ (tests/test_e2e_gpu.py runs the same check on the sequential scan) -- with the
+    10 000-column batches of BASELINE config 1 running as 16 certified chunks per window."""
+    import test_e2e_gpu as e2e
+    sgold = dict(np.load(os.path.join(GOLD, "stitch_cases.npz")))
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    m = m.to("cuda").eval()
+    seen = []
+    plain = m.predict_on_batch
+
+    def recording(batch):
+        out = plain(batch)
+        seen.append((tuple(batch.counts_matrix.shape), m.engine().split()))
+        return out
+    m.predict_on_batch = recording
+    for case in ("mini", "cfg1"):
+        e2e.test_stitched_fastq_identical_to_reference(sgold, m, case)
+    split = [(shape, info) for shape, info in seen if info["chunks"] > 1]
+    print("split calls:", [(shape, info["chunks"], info["status"]) for shape, info in split])
+    assert split and all(info["status"] == "certified" for _, info in split)
+    assert any(shape[1] == 10000 and info["chunks"] == 16 for shape, info in split)
