@@ -951,7 +951,8 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     if (x_host)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
     {
-        const int vec = (F % 2 == 0) ? 2 : 1;
+        // float2 copies need 8-byte aligned rows: an even feature count and a caller's pointer that is not on an odd float
+        const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 8 == 0) ? 2 : 1;
         const size_t n = cols * F / vec;
         hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
                            x_dev, m->xv, sp, (int)F, vec);
