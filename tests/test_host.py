@@ -459,3 +459,35 @@ def test_c_host_compiles_and_links_against_the_header(tmp_path):
     (the reference-side binding could equally be cffi, which medaka already uses for libmedaka)."""
     exe = _build_c_host(tmp_path)
     assert os.path.getsize(exe) > 0
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirror of every struct of include/medaka_amd.h (medaka_amd/lib.py) has the size and the field offsets
+    gcc gives the C declaration: a field added on one side only cannot go unnoticed."""
+    import ctypes
+    import subprocess
+    from medaka_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = {"mdk_gru_desc": lib.GruDesc, "mdk_rl_desc": lib.RlDesc, "mdk_rl_timing": lib.RlTiming,
+             "mdk_gru_timing": lib.GruTiming, "mdk_gru_split": lib.GruSplit, "mdk_split_shape": lib.SplitShape}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "medaka_amd.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" {fname}:%zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", exe])
+    out = subprocess.check_output([exe], text=True).strip().split("\n")
+    assert len(out) == len(pairs)
+    for line in out:
+        cname, size, *fields = line.split()
+        cls = pairs[cname]
+        assert int(size) == ctypes.sizeof(cls), cname
+        assert len(fields) == len(cls._fields_), cname
+        for item in fields:
+            fname, off = item.split(":")
+            assert getattr(cls, fname).offset == int(off), (cname, fname)
