@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import weight_set
+from conftest import GOLD, weight_set
 from medaka_amd import engine, integration, lib, models, synth
 from medaka_amd.torch_ext import Batch
 from oracle import oracle
@@ -423,6 +423,67 @@ def test_model_api_predict_on_batch(gold):
     ph = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
     assert np.abs(ph - ref).max() <= 2e-3
     assert (ph.argmax(-1) == ref.argmax(-1)).mean() > 0.999
+
+
+def test_majority_vote_model(gold):
+    """Row a8 (majority_vote_model.py:37-53) on the device, against the goldens of the unmodified reference."""
+    m = models.MajorityVoteModel().to("cuda").eval()
+    for cname, ref in gold["majority_outputs"].items():
+        x = gold["gru_inputs"][cname]
+        p = m.predict_on_batch(Batch(counts_matrix=torch.from_numpy(x))).numpy()
+        assert np.abs(p - ref).max() <= 2e-7
+    assert np.abs(engine.majority_forward_host(gold["gru_inputs"]["uniform"]) -
+                  oracle.c_majority_forward(gold["gru_inputs"]["uniform"])).max() <= 2e-7
+
+
+# ---- SURVEY 8f rows f2 / f3: device-side normalisation and decode ---------------------------------
+def _normalise_on_device(counts, depth):
+    """`mdk_normalise_counts_dev` on raw buffers: what `_post_process_pileup` (features.py:907-911,926) does on the host."""
+    L = engine._lib.load()
+    n_cols = counts.shape[0] * counts.shape[1]
+    F = counts.shape[2]
+    cd, dd, xd = engine.DeviceBuffer(counts.nbytes), engine.DeviceBuffer(depth.nbytes), engine.DeviceBuffer(n_cols * F * 4)
+    cd.upload(np.ascontiguousarray(counts)); dd.upload(np.ascontiguousarray(depth))
+    engine._lib.check(L.mdk_normalise_counts_dev(cd.ptr, dd.ptr, n_cols, F, xd.ptr, 0, None), "normalise")
+    x = xd.download(counts.shape, np.float32)
+    for b in (cd, dd, xd):
+        b.free()
+    return x
+
+
+@pytest.mark.parametrize("name", ["d60", "d300"])
+def test_counts_in_decoded_out_matches_reference(gold, engines, name):
+    """tests/golden/pcie_diet.npz holds raw pileup counts, the features the UNMODIFIED reference's
+    `_post_process_pileup` makes of them, its probabilities and its decoded consensus (oracle/make_golden.py)."""
+    d = np.load(os.path.join(GOLD, "pcie_diet.npz"))
+    counts, depth = d[f"{name}/counts"], d[f"{name}/depth"]
+    e = engines("trained")
+    # f2: the device's normalisation is bit-identical to the reference's float64-divide-then-round
+    assert np.array_equal(_normalise_on_device(counts, depth), d[f"{name}/features"])
+    # whole path: raw counts in, probabilities + decoded classes out
+    probs, cls, pmax = e.forward_counts_host(counts, depth, probs=True, decoded=True)
+    assert np.array_equal(probs, e.forward_host(d[f"{name}/features"]))
+    _check(probs, d[f"{name}/probs"], what=f"counts-in {name}", strict_argmax=True)
+    # f3: first-maximum argmax and its probability, bit for bit
+    assert np.array_equal(cls, probs.argmax(-1)) and np.array_equal(pmax, probs.max(-1))
+    cls2, pmax2 = e.forward_decoded_host(d[f"{name}/features"])
+    assert np.array_equal(cls2, cls) and np.array_equal(pmax2, pmax)
+    n_q = n_bad = 0
+    for w in range(cls.shape[0]):
+        seq, qual = engine.decode_consensus(cls[w], pmax[w], with_qualities=True)
+        assert (seq, qual) == oracle.decode_consensus(probs[w], with_qualities=True)
+        assert seq == str(d[f"{name}/seq"][w])                      # identical consensus (labels.py:1053-1085)
+        ref_q = str(d[f"{name}/qual"][w])
+        n_q += len(ref_q)
+        n_bad += sum(a != b for a, b in zip(qual, ref_q))
+    assert n_bad <= 0.01 * n_q       # a quality char may sit on a truncation boundary of -10 log10(1 - p)
+    # model-level entry
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weight_set(gold, "trained").items()})
+    m = m.to("cuda").eval()
+    assert np.array_equal(m.predict_on_counts(counts, depth).numpy(), probs)
+    c3, p3 = m.predict_on_counts(counts.astype(np.int32), depth, decoded=True)       # any integer dtype that fits
+    assert np.array_equal(c3.numpy(), cls) and np.array_equal(p3.numpy(), pmax)
 
 
 def test_decode_dev_first_maximum_and_nan():

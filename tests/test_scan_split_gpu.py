@@ -250,6 +250,40 @@ def test_model_api_takes_the_split_path(gold):
     assert np.abs(seq - out).max() <= 2e-6
 
 
+def test_counts_in_decoded_out_at_full_size_through_the_split_scan(gold):
+    """SURVEY 8f rows f2 / f3 at BASELINE configs[1] (200 x 10000), as a SPLIT call: raw uint16 counts + depth in
+    (`mdk_gru_forward_counts`), probabilities and decoded (class, probability) out.  The device's normalisation is
+    the reference's float64-divide-then-round (features.py:907-911,926) bit for bit, so counts-in == features-in bit
+    for bit; the decode is numpy's first-maximum argmax (labels.py:1061-1065) on exactly those probabilities."""
+    from test_parity_gpu import _normalise_on_device
+    B, T = 200, 10000
+    raws = [synth.counts_windows(8, T, depth=50, seed=300 + s, raw=True) for s in range(25)]
+    counts = np.concatenate([r["counts"] for r in raws])
+    depth = np.concatenate([r["depth"] for r in raws])
+    feats = oracle.normalise_counts(counts, depth)
+    assert np.array_equal(_normalise_on_device(counts, depth), feats)          # f2 on all 2 M columns
+    e = engine.GruEngine(gold["weights_trained"])
+    probs, cls, pmax = e.forward_counts_host(counts, depth, probs=True, decoded=True)
+    info = e.split()
+    assert info["status"] == "certified" and info["chunks"] == 5, info
+    assert np.array_equal(probs, e.forward_host(feats))                        # counts-in == features-in
+    assert e.split()["status"] == "certified"
+    assert np.array_equal(cls, probs.argmax(-1)) and np.array_equal(pmax, probs.max(-1))      # f3
+    cls2, pmax2 = e.forward_decoded_host(feats)
+    assert np.array_equal(cls2, cls) and np.array_equal(pmax2, pmax)
+    seq = _sequential(e, feats)
+    assert np.abs(probs - seq).max() <= 2e-6 and np.array_equal(cls, seq.argmax(-1))
+    # consensus strings: the engine's decode of (class, probability) against the restated reference decode of the
+    # sequential scan's probabilities (pinned to labels.py by tests/test_oracle.py)
+    for w in (0, 77, 199):
+        assert engine.decode_consensus(cls[w], pmax[w]) == oracle.decode_consensus(seq[w])
+    # 16 windows of it against the PyTorch-CPU oracle fed the HOST-normalised features
+    torch.set_num_threads(usable_cores())
+    ref = oracle.make_torch_oracle(gold["weights_trained"]).predict(feats[:16]).numpy()
+    _check(probs[:16], ref, what="counts-in split call", strict_argmax=True)
+    e.close()
+
+
 def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
     """Regression (found by the split scan's certificate): in half-precision mode 16-window work-groups of a batch
     with an odd number of 8-window tiles ran their surplus lanes on a copy of the last window -- with the fused
