@@ -66,6 +66,8 @@ typedef struct {
     float total_ms;       /* first kernel start -> last kernel end (device-resident region) */
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
+    int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
+                             "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both) */
 } mdk_gru_timing;
 
 /* What the last forward did about splitting the scan (option "scan_split" below). */
@@ -83,6 +85,9 @@ typedef struct {
     int fallbacks;    /* rejected certificates since the model was created (each cost one repeated forward) */
     int audited;      /* 1: this call was also run as the sequential scan and the two results compared in full */
     float audit_max_dp; /* largest |p_split - p_sequential| of that comparison */
+    int spot_audits;    /* standing spot audits completed since the model was created ("scan_split_spot") */
+    int spot_failures;  /* ... of which found a difference above the audit tolerance (the split is then turned off) */
+    float spot_max_dp;  /* largest |p_split - p_sequential| any spot audit has seen */
 } mdk_gru_split;
 
 /*
@@ -130,6 +135,11 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
 /* Tuning knobs (no reference counterpart):
  *   "rec_windows_per_tile" = 0 (auto) | 4 | 8      recurrence work-group granularity
  *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
+ *   "fuse_proj"            = 1 (auto) | 0 | 2 (always)  layers >= 1: the input projection runs inside the recurrence
+ *                                                   kernel, strip by strip, and its result never exists in HBM
+ *                                                   (bit-identical to the separate GEMM; fp32-parity mode, 8-window
+ *                                                   work-groups, T % 8 == 0; auto: when the call fills the chip, i.e.
+ *                                                   whenever "overlap_gemm" would not apply; environment MDK_FUSE_PROJ)
  *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
@@ -157,6 +167,13 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   results are compared in full (4e-6; half precision 4e-4); a mismatch
  *                                                   delivers the sequential result and turns the split off.  One extra
  *                                                   forward per model.  2: every certified call (debug), 0: never
+ *   "scan_split_spot"      = 1 | 0                  standing spot audit: after a certified call 4 of its windows (rotating) are
+ *                                                   recomputed as the sequential scan by a shadow engine on a low-priority
+ *                                                   stream of its own, under the caller's next forwards (one audit in flight
+ *                                                   at a time), and compared with what was delivered (4e-6 / 4e-4): a
+ *                                                   mismatch turns the split off for the model and is reported on stderr and
+ *                                                   in mdk_gru_split.spot_failures.  Costs two small device copies per
+ *                                                   audited call and ~0.7 GB of workspace
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
@@ -176,6 +193,9 @@ int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);
 
 /* Chunks, margin and certificate of the last forward (see "scan_split"). */
 int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out);
+/* Waits for the standing spot audit in flight, if any ("scan_split_spot"), and folds its result into the spot_* fields
+ * that mdk_gru_get_split reports (normally the next forward does that when it finds the audit finished). */
+int mdk_gru_spot_wait(mdk_gru *m);
 
 /* The shape arithmetic of "scan_split" on its own (no device needed): how a batch of B windows of T columns would be
  * split by a process that is one of `gpu_share` on its GPU, with option values `scan_split` (1 auto, n >= 2 forced) and

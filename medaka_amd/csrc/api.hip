@@ -20,6 +20,7 @@
 #include "layout.hpp"
 #include "head.hpp"
 #include "rec_mfma.hpp"
+#include "rec_fused.hpp"
 #include "scan_split.hpp"
 
 using namespace mdk;
@@ -62,6 +63,7 @@ struct mdk_gru {
     int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
     size_t max_rows_per_pass = 0;   // 0 = kMaxRowsPerPass
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
+    int opt_fuse_proj = 1;      // layers >= 1: projection fused into the recurrence (rec_fused.hpp): 0 off, 1 when the call fills the chip, 2 always
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
     int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
@@ -102,6 +104,23 @@ struct mdk_gru {
     int split_audited_key = 0;               // margin | precision << 16 whose first certified call has been audited (0 = none yet)
     float *audit = nullptr;                  // the sequential scan's probabilities of an audited call
     size_t audit_cap = 0;
+    // standing spot audit of certified split calls (run_forward / spot_submit): a shadow engine on the same weights
+    // re-runs a few windows of a certified call as the SEQUENTIAL scan on its own low-priority stream, under the
+    // caller's next forwards, and the two results are compared when it has finished
+    std::vector<std::vector<float>> host_weights;   // what mdk_gru_create was given (the shadow is created from it)
+    mdk_gru *shadow = nullptr;
+    int opt_split_spot = 1;                  // 0 off, 1 on (one audit in flight at a time)
+    hipStream_t spot_stream = nullptr;
+    hipEvent_t spot_ready = nullptr, spot_done = nullptr;
+    bool spot_in_flight = false;
+    float *spot_x = nullptr, *spot_p = nullptr, *spot_q = nullptr;
+    size_t spot_cap = 0;                     // columns the three buffers hold
+    unsigned *spot_flag = nullptr, *spot_host = nullptr;
+    int spot_next = 0, spot_n = 0, spot_precision = 0;
+    long spot_count = 0;
+    int spot_failures = 0;
+    float spot_worst = 0.f;
+    bool is_shadow = false;
     // timing
     bool timing = false;
     mdk_gru_timing last{};
@@ -120,6 +139,14 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
     if (m->split_host) (void)hipHostFree(m->split_host);
+    if (m->spot_stream) (void)hipStreamSynchronize(m->spot_stream);
+    if (m->shadow) mdk_gru_destroy(m->shadow);
+    (void)hipSetDevice(m->device);
+    free_dev(m->spot_x); free_dev(m->spot_p); free_dev(m->spot_q); free_dev(m->spot_flag);
+    if (m->spot_host) (void)hipHostFree(m->spot_host);
+    if (m->spot_ready) (void)hipEventDestroy(m->spot_ready);
+    if (m->spot_done) (void)hipEventDestroy(m->spot_done);
+    if (m->spot_stream) (void)hipStreamDestroy(m->spot_stream);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -152,6 +179,16 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->device = device;
     m->D = D;
     m->layers.resize(L);
+    for (int i = 0; i < n_weights; ++i) {       // sizes in the state_dict order of the header
+        size_t n;
+        if (i >= 4 * L * D) n = (i == 4 * L * D) ? (size_t)C * D * H : (size_t)C;
+        else {
+            const int l = i / (4 * D), kind = i % 4;
+            const size_t K = (l == 0) ? I : D * H;
+            n = kind == 0 ? (size_t)kG * K : kind == 1 ? (size_t)kG * kH : (size_t)kG;
+        }
+        m->host_weights.emplace_back(weights[i], weights[i] + n);
+    }
     // process-wide defaults of the split scan (the options of the same names override them per model)
     if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
@@ -295,6 +332,9 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
+    if (const char *e = getenv("MDK_FUSE_PROJ")) m->opt_fuse_proj = std::min(std::max(atoi(e), 0), 2);
 
     *out = m;
     return MDK_OK;
@@ -330,6 +370,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_ablate = value;
     } else if (!strcmp(key, "fuse_l0")) {
         m->opt_fuse_l0 = value ? 1 : 0;
+    } else if (!strcmp(key, "fuse_proj")) {
+        if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "fuse_proj must be 0 (off), 1 (auto) or 2 (always)");
+        m->opt_fuse_proj = value;
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
     } else if (!strcmp(key, "deferred_store")) {
@@ -346,6 +389,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
+    } else if (!strcmp(key, "scan_split_spot")) {
+        if (value < 0 || value > 1) return fail(MDK_ERR_ARG, "scan_split_spot must be 0 or 1");
+        m->opt_split_spot = value;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
@@ -380,6 +426,15 @@ extern "C" int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out) {
     return MDK_OK;
 }
 extern "C" int mdk_gru_device(const mdk_gru *m) { return m ? m->device : -1; }
+static int spot_poll(mdk_gru *m, bool wait);
+static void report_spot(mdk_gru *m);
+extern "C" int mdk_gru_spot_wait(mdk_gru *m) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = spot_poll(m, true);
+    report_spot(m);
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -571,8 +626,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     constexpr int kOvMaxWgs = 208;   // profiles/run_overlap_sweep.sh: +10 % at 128 work-groups, +5 % at 160, +-1 % at 200-256
     const bool ablated = (abl != 0 && !hp && nq <= 2);
     const bool can_chunk = D == 2 && !ablated && T >= 2048 && T % (2 * kGemmSteps) == 0;
-    const bool overlap = m->opt_overlap && can_chunk && L >= 2 &&
-                         (n_wg * D * m->opt_gpu_share <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
+    const bool overlap_ok = m->opt_overlap && can_chunk && L >= 2 &&
+                            (n_wg * D * m->opt_gpu_share <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
+    // Layers >= 1 in the throughput regime (every CU holds a recurrence work-group: nothing is idle to hide a projection
+    // GEMM under): the projection runs INSIDE the recurrence kernel, strip by strip, and gi never exists in HBM
+    // (rec_fused.hpp; bit-identical to the GEMM + recurrence pair).  fp32-parity mode, 8-window work-groups, T a
+    // multiple of the strip.  "fuse_proj" = 2 prefers it to the side-stream GEMM as well.
+    const bool fuse_proj = L >= 2 && !hp && nq == 2 && !ablated && T % kFusedSteps == 0 &&
+                           (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && !overlap_ok));
+    const bool overlap = overlap_ok && !fuse_proj;
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
     const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
     const bool stream_out = io_out && can_chunk && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
@@ -616,6 +678,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         const float *gi_src = (l == 1 && gemm_done) ? gi_l1 : m->gi;
         const bool fuse = (l == 0) && fuse0;
         const int *cond = fuse ? m->oor_flag : nullptr;
+        const bool fused_proj = l >= 1 && fuse_proj;
         // device-resident x: the packing of all but the first slab pair runs on the side stream under the
         // first recurrence phases instead of in front of them (0.25 ms of k_pack_x at 200 x 10000)
         const bool dev_slabs = !io_in && fuse && can_chunk && l == 0 && m->opt_overlap;
@@ -643,7 +706,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         if (l == 0) {
             if (!slabs) launch_gi_small();
         } else {
-            if (!(l == 1 && gemm_done)) launch_gemm(Ld, in, m->gi, s, 0, (T + kGemmSteps - 1) / kGemmSteps);
+            if (!(l == 1 && gemm_done) && !fused_proj) launch_gemm(Ld, in, m->gi, s, 0, (T + kGemmSteps - 1) / kGemmSteps);
         }
         if ((rc = tm.end())) return rc;
         size_t rspan = 0;
@@ -658,6 +721,18 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
          else MDK_LAUNCH_REC_T(NQV, XIN, HPF, A, false, CND, WANT); } while (0)
         // production instantiations
         auto launch = [&](bool xin, const int *cnd, int want) {
+            if (fused_proj) {
+                if (D == 2)
+                    hipLaunchKernelGGL((k_rec_fused<8>), rgrid, dim3(512), fused_lds_bytes(8), s, in, Ld.wih_frag, Ld.bias_gi,
+                                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi,
+                                       Ld.up_scale_rec, kActScale, reverse_mask, rs0, rns);
+                else
+                    hipLaunchKernelGGL((k_rec_fused<4>), rgrid, dim3(512), fused_lds_bytes(4), s, in, Ld.wih_frag, Ld.bias_gi,
+                                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi,
+                                       Ld.up_scale_rec, kActScale, reverse_mask, rs0, rns);
+                m->last.fused_layers |= 1 << l;
+                return;
+            }
             if (hp) {
                 if (nq == 1) { if (xin) MDK_LAUNCH_REC(1, true, true, 0, cnd, want); else MDK_LAUNCH_REC(1, false, true, 0, cnd, want); }
                 else if (nq == 2) { if (xin) MDK_LAUNCH_REC(2, true, true, 0, cnd, want); else MDK_LAUNCH_REC(2, false, true, 0, cnd, want); }
@@ -938,10 +1013,8 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
         HIP_TRY(hipMalloc((void **)&m->xv, cols * F * sizeof(float)));
         m->xv_cap = cols * F;
     }
-    if (!m->split_flag) {
-        HIP_TRY(hipMalloc((void **)&m->split_flag, kSplitFlagWords * sizeof(unsigned)));
-        HIP_TRY(hipHostMalloc((void **)&m->split_host, kSplitFlagWords * sizeof(unsigned), hipHostMallocDefault));
-    }
+    if (!m->split_flag) HIP_TRY(hipMalloc((void **)&m->split_flag, kSplitFlagWords * sizeof(unsigned)));
+    if (!m->split_host) HIP_TRY(hipHostMalloc((void **)&m->split_host, kSplitFlagWords * sizeof(unsigned), hipHostMallocDefault));
     int rc = ensure_workspace(m, (((size_t)Bv + kTileWin - 1) / kTileWin * kTileWin) * (size_t)sp.Tv);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(m->split_flag, 0, kSplitFlagWords * sizeof(unsigned), s));
@@ -993,25 +1066,129 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     return MDK_OK;
 }
 
+// ---- standing spot audit ------------------------------------------------------------------------------------------
+// The certificate argues from the states at the junctions and the first-call audit looks at one batch.  This looks at
+// what is delivered, on every kind of input the model meets, for as long as it runs: after a certified call, kSpotWin
+// windows of it (a rotating choice) are copied aside with their split-scan probabilities, a SHADOW engine (same
+// weights, sequential scan, its own small workspace and a stream of its own) recomputes them under the caller's next
+// forwards -- two 4-window work-groups next to the 250 of a split forward -- and the comparison is read when the next
+// call finds it finished.  One audit in flight at a time.  A difference above the audit tolerance cannot take the
+// delivered batch back; it turns the split off for the model, counts in mdk_gru_split.spot_failures and says so on
+// stderr.  Cost: two device-to-device copies of 4 windows per audited call (measured: bench.py `spot_audit`).
+constexpr int kSpotWin = 4;
+
+static int spot_poll(mdk_gru *m, bool wait) {
+    if (!m->spot_in_flight) return MDK_OK;
+    hipError_t e = wait ? hipEventSynchronize(m->spot_done) : hipEventQuery(m->spot_done);
+    if (e == hipErrorNotReady) return MDK_OK;
+    if (e != hipSuccess) return fail(MDK_ERR_DEVICE, "spot audit: %s", hipGetErrorString(e));
+    m->spot_in_flight = false;
+    float dp;
+    memcpy(&dp, &m->spot_host[0], sizeof(float));
+    m->spot_count++;
+    m->spot_worst = std::max(m->spot_worst, dp);
+    if (!(dp <= (m->spot_precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol))) {
+        m->spot_failures++;
+        m->split_disabled = true;
+        fprintf(stderr, "[medaka_amd] split scan: a spot audit found |p_split - p_sequential| = %.3g on %d windows of a "
+                        "CERTIFIED call (tolerance %.1g): the split scan is now off for this model; results delivered "
+                        "before this point may differ from the sequential scan by that much\n",
+                dp, m->spot_n, (double)(m->spot_precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol));
+    }
+    return MDK_OK;
+}
+
+static int spot_submit(mdk_gru *m, const float *x_dev, const float *probs_dev, int B, int T, hipStream_t s) {
+    if (!m->opt_split_spot || m->is_shadow || m->spot_in_flight || m->split_disabled) return MDK_OK;
+    const size_t F = m->desc.num_features, C = m->desc.num_classes;
+    if (!m->shadow) {
+        std::vector<const float *> ptrs;
+        for (auto &w : m->host_weights) ptrs.push_back(w.data());
+        int rc = mdk_gru_create(&m->desc, ptrs.data(), (int)ptrs.size(), m->device, &m->shadow);
+        if (rc) return rc;
+        m->shadow->is_shadow = true;
+        m->shadow->opt_scan_split = 0;
+        m->shadow->opt_overlap = 0;          // (no second gi buffer; 4 windows do not need the side stream)
+        m->shadow->opt_split_spot = 0;
+        std::vector<std::vector<float>>().swap(m->shadow->host_weights);
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = numerically greatest = LOWEST priority
+        HIP_TRY(hipStreamCreateWithPriority(&m->spot_stream, hipStreamNonBlocking, lo));
+        HIP_TRY(hipEventCreateWithFlags(&m->spot_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->spot_done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **)&m->spot_flag, sizeof(unsigned)));
+        HIP_TRY(hipHostMalloc((void **)&m->spot_host, sizeof(unsigned), hipHostMallocDefault));
+    }
+    const int nw = std::min(kSpotWin, B);
+    const int w0 = std::min(m->spot_next % B, B - nw);
+    m->spot_next = (w0 + nw) % B;
+    const size_t cols = (size_t)nw * T;
+    if (cols > m->spot_cap) {
+        free_dev(m->spot_x); free_dev(m->spot_p); free_dev(m->spot_q);
+        m->spot_x = m->spot_p = m->spot_q = nullptr;
+        m->spot_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->spot_x, cols * F * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->spot_p, cols * C * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&m->spot_q, cols * C * sizeof(float)));
+        m->spot_cap = cols;
+    }
+    HIP_TRY(hipMemcpyAsync(m->spot_x, x_dev + (size_t)w0 * T * F, cols * F * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->spot_p, probs_dev + (size_t)w0 * T * C, cols * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(m->spot_ready, s));
+    HIP_TRY(hipStreamWaitEvent(m->spot_stream, m->spot_ready, 0));
+    HIP_TRY(hipEventSynchronize(m->spot_ready));     // the caller may reuse x / probs as soon as the call returns
+    mdk_gru *sh = m->shadow;
+    sh->precision = m->precision;
+    sh->desc.normalise = m->desc.normalise;
+    int rc = run_passes(sh, m->spot_x, nw, T, m->spot_q, m->spot_stream, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(m->spot_flag, 0, sizeof(unsigned), m->spot_stream));
+    hipLaunchKernelGGL(k_split_audit, dim3((unsigned)std::min<size_t>((cols * C + 255) / 256, 256)), dim3(256), 0, m->spot_stream,
+                       (const float *)m->spot_p, (const float *)m->spot_q, cols * C, m->spot_flag);
+    HIP_TRY(hipMemcpyAsync(m->spot_host, m->spot_flag, sizeof(unsigned), hipMemcpyDeviceToHost, m->spot_stream));
+    HIP_TRY(hipEventRecord(m->spot_done, m->spot_stream));
+    HIP_TRY(hipGetLastError());
+    m->spot_in_flight = true;
+    m->spot_n = nw;
+    m->spot_precision = m->precision;
+    return MDK_OK;
+}
+
+static void report_spot(mdk_gru *m) {
+    m->last_split.spot_audits = (int)std::min<long>(m->spot_count, 0x7fffffff);
+    m->last_split.spot_failures = m->spot_failures;
+    m->last_split.spot_max_dp = m->spot_worst;
+}
+
 // one call: split scan when the shape is latency-bound and the certificate holds, the sequential passes otherwise
 static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
                        const float *x_host, float *probs_host) {
     SplitPlan sp;
-    m->last_split.chunks = 1; m->last_split.margin = 0; m->last_split.columns = T; m->last_split.max_delta = 0.f;
-    m->last_split.audited = 0; m->last_split.audit_max_dp = 0.f;
+    int rc = spot_poll(m, false);
+    if (rc) return rc;
+    const int fallbacks = m->last_split.fallbacks;
+    memset(&m->last_split, 0, sizeof(m->last_split));
+    m->last_split.chunks = 1; m->last_split.columns = T; m->last_split.fallbacks = fallbacks;
     m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
-    static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug: deliver a rejected split as it is
+    report_spot(m);
+#ifdef MDK_DEBUG_HOOKS
+    static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug builds only: deliver a rejected split as it is
+#else
+    const bool keep = false;
+#endif
     while (plan_split(m, B, T, sp)) {
         bool ok = false;
-        int rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
+        rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
         if (rc) return rc;
+        report_spot(m);
         if (keep) return MDK_OK;
         if (ok) {
             // Audit: the first certified call of a model (and the first at every margin / precision it moves to) is ALSO run as
             // the sequential scan, and the two results are compared in full -- the certificate argues from the states
             // at the junctions, the audit looks at what is delivered.  One extra forward per model, not per call.
             const int audit_key = sp.G | (m->precision << 16) | (1 << 24);
-            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_key == audit_key)) return MDK_OK;
+            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_key == audit_key))
+                return spot_submit(m, x_dev, probs_dev, B, T, s);
             const size_t n = (size_t)B * T * m->desc.num_classes;
             if (n > m->audit_cap) {
                 free_dev(m->audit); m->audit = nullptr; m->audit_cap = 0;
@@ -1036,6 +1213,8 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
                 return MDK_OK;
             }
             // never seen: certified junctions, different probabilities.  The sequential result is already there.
+            fprintf(stderr, "[medaka_amd] split scan: the first-call audit found |p_split - p_sequential| = %.3g behind a certified "
+                            "split (margin %d): the sequential result is delivered and the split scan is off for this model\n", dp, sp.G);
             m->last_split.status = MDK_SPLIT_REJECTED;
             m->last_split.fallbacks++;
             m->split_disabled = true;
@@ -1045,18 +1224,26 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
             return MDK_OK;
         }
         // Some junction did not merge: this model remembers further back than the margin.  Auto mode tries again with
-        // twice the margin -- and keeps it for later calls -- while the shape still splits and the margin is at most
-        // kSplitMarginMax; after that (a model with a very long or chaotic memory) the sequential scan decides, for this
-        // call and for every later one.  A forced chunk count is not second-guessed: the call is answered sequentially.
+        // twice the margin and keeps it for later calls (said once on stderr).  A shape that no longer splits at the new
+        // margin is answered sequentially -- this call only; the model is given up (sequential scans from then on) only by
+        // a rejection AT kSplitMarginMax: a very long or chaotic memory.  A forced chunk count is not second-guessed: the
+        // call is answered sequentially.
         m->last_split.fallbacks++;
         if (m->opt_scan_split != 1) break;
         const int next = 2 * sp.G;
-        if (next > kSplitMarginMax) { m->split_disabled = true; break; }
+        if (next > kSplitMarginMax) {
+            m->split_disabled = true;
+            fprintf(stderr, "[medaka_amd] split scan: junction states still differ by %.3g at a margin of %d columns: this model "
+                            "runs as sequential scans from now on\n", m->last_split.max_delta, sp.G);
+            break;
+        }
         m->split_margin_cur = next;
-        SplitPlan probe;
-        if (!plan_split(m, B, T, probe)) { m->split_disabled = true; break; }   // (this shape no longer splits at that margin)
+        fprintf(stderr, "[medaka_amd] split scan: junction states differed by %.3g at a margin of %d columns: margin %d from now on\n",
+                m->last_split.max_delta, sp.G, next);
     }
-    return run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
+    rc = run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
+    report_spot(m);
+    return rc;
 }
 
 extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,

@@ -1,0 +1,293 @@
+// GRU layer >= 1 with its input projection FUSED into the recurrence: gi never goes to HBM.
+//
+// Unfused (gi_proj.hpp + rec_mfma.hpp) a layer with K = 256 inputs writes gi = x W_ih^T + b as fp32 -- 3072 bytes per
+// column and direction pair -- and the recurrence reads it back: 13.9 of the 24.6 GB a 200 x 10000 forward moves
+// (profiles/traffic.json, round 3), and 2.7 ms of projection GEMM in front of a 2.2 ms recurrence.  In the throughput
+// regime (split scan, or batches that fill the chip by themselves) every CU holds one recurrence work-group whose
+// matrix pipe idles about half of every step, and the GEMM's own work-group shape is already the recurrence's:
+// (8 windows x 8 steps) x 384 gate columns of ONE direction, with the accumulator element of lane (g, c), register
+// 2q + tt of row-tile mt being exactly the pre-activation that lane consumes at step 2 mt + tt for window 2g + q
+// (gi_proj.hpp epilogue == rec_mfma.hpp `gp[q]`).  So this kernel alternates, per strip of 8 scan steps:
+//
+//   projection phase   the strip's 64 rows x K of previous-layer activations sit in LDS as fp16 hi/lo A-fragments
+//                      (64 KB, staged during the PREVIOUS strip's steps); every wave runs the k_gi_gemm inner loop for
+//                      its 16 hidden units x 3 gates of this direction: 8 k-steps x 4 row-tiles x 3 gates x 3 split
+//                      products = 288 MFMAs back to back, W_ih fragments streaming from L2 one k-step ahead;
+//                      scale + folded bias applied in place: 48 accumulator registers per lane = the strip's gi;
+//   recurrence phase   8 steps of the k_rec_mfma step (W_hh in registers, h image in LDS, one barrier per step) taking
+//                      gi from those registers; under steps 0..3 each thread requests its 4 pieces (8 floats) of the
+//                      NEXT strip's activations, under steps 2..5 it splits them to fp16 hi/lo and stores them in LDS.
+//
+// Same MFMAs in the same order on the same operands as the unfused pair, same fmaf for scale + bias, same gate
+// arithmetic: the results are BIT-IDENTICAL to k_gi_gemm + k_rec_mfma (tests/test_parity_gpu.py
+// ::test_fused_projection_agrees_bitwise), so every parity result of the unfused path carries over.
+// HBM per column and direction: 1024 B of activations in (both input directions) + 512 B of h out, against
+// 512 + 1536 (GEMM, its share) + 1536 + 512 (recurrence).
+// fp32-parity mode (fp16 hi/lo split), 8-window work-groups, GRU cell; T, s0, ns multiples of 8.
+#pragma once
+#include "common.hpp"
+#include "gi_proj.hpp"
+#include "layout.hpp"
+#include "rec_mfma.hpp"
+
+namespace mdk {
+
+constexpr int kFusedSteps = 8;                         // scan steps per strip = rows 2 mt + tt of 4 MFMA row-tiles
+constexpr int kFusedMT = kFusedSteps / 2;
+__host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS) { return (size_t)2 * kFusedMT * KSTEPS * 64 * 16; }
+
+template <int KSTEPS>   // K = 32 * KSTEPS = DIN * 128 input features
+__global__ __launch_bounds__(512, 2) void k_rec_fused(
+    const float *__restrict__ act_in,   // act_t of the previous layer (|x| < 1)
+    const half8 *__restrict__ wihfrag,  // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]   (as k_gi_gemm)
+    const float *__restrict__ bias,     // [D][384] folded bias                              (as k_gi_gemm)
+    const half8 *__restrict__ wfrag,    // W_hh B-fragments [D][8][4][3][2][64]              (as k_rec_mfma)
+    const float *__restrict__ b_hn,     // [D][128]
+    float *__restrict__ out,            // act_t of this layer
+    int n_tiles, int T, int D,
+    const float *__restrict__ inv_scale_rec_p, const float *__restrict__ inv_scale_gi_p,
+    const float *__restrict__ up_scale_rec_p, float a_scale,
+    int reverse_mask, int s0, int ns)
+{
+    constexpr int DIN = KSTEPS / 4;
+    constexpr int NP = DIN * 128;               // 8-float pieces per activation block
+    constexpr int MT = kFusedMT;
+    constexpr int NPIECE = kFusedSteps * NP / 512;   // pieces per thread and strip
+    static_assert(NPIECE == 2 || NPIECE == 4, "staging schedule below assumes 2 or 4 pieces per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *xs = reinterpret_cast<half8 *>(smem);            // [split 2][mt MT][KSTEPS][64 lanes]
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
+    __builtin_amdgcn_s_setprio(MDK_REC_PRIO);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int d = blockIdx.y;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    const bool reverse = (reverse_mask >> d) & 1;
+    const float inv_scale = inv_scale_rec_p[d];
+    const float c_sig = -inv_scale * 1.44269504088896340736f;
+    const float c_tanh = 2.0f * inv_scale * 1.44269504088896340736f;
+
+    half8 wf[4][3][2];
+    {
+        const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * 24) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
+    }
+    for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+
+    const int u = 16 * w8 + c;
+    const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
+    // projection epilogue constants (gi_proj.hpp): gi = acc * (inv_scale_gi * os) + bias * os, os = the recurrence's scale
+    const float os = up_scale_rec_p[d];
+    const float gi_scale = inv_scale_gi_p[d] * os;
+    float bv[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) bv[nt] = bias[(size_t)d * kG + nt * kH + u] * os;
+
+    const long tstep = reverse ? -1 : 1;
+    const int s_end = s0 + ns;
+    const int t_first = reverse ? (T - 1 - s0) : s0;
+    float *op[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, q, lane);
+    const long ostride = tstep * (long)(D * 1024);
+    float hprev[2] = {0.f, 0.f};
+
+    const int rd_off = g * kHGroupStride + c * 16;
+    const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride + (4 * g) * 16 + (c & 7) * 2;
+
+    // ---- staging of a strip's activations (the k_gi_gemm staging, one piece at a time; scan step tau of the strip is
+    // row 2 mt + tt = tau of the M-tile whatever the direction: a reversed scan stages its columns in descending order)
+    const float *in_tile = act_in + act_block(DIN, tile, T, 0);
+    struct Piece { floatx4 v0, v1; };
+    auto piece_load = [&](int strip, int it) {
+        const int P = it * 512 + tid;
+        const int tau = P / NP, j = P % NP;
+        const int gg = j & 3, qq = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
+        const int piece = chunk * 16 + qq * 8 + gg * 2 + half;
+        const int s = strip * kFusedSteps + tau;
+        const int t = reverse ? (T - 1 - s) : s;
+        const float *src = in_tile + (size_t)t * (DIN * 1024) + piece * 8;
+        Piece p;
+        p.v0 = *reinterpret_cast<const floatx4 *>(src);
+        p.v1 = *reinterpret_cast<const floatx4 *>(src + 4);
+        return p;
+    };
+    auto piece_store = [&](int it, Piece p) {
+        // the request stays in flight until HERE: without this the compiler multiplies by a_scale right behind the load
+        // and waits for it in the step that issued it (seen in the ISA: vmcnt(0) under the next MFMAs)
+        asm volatile("" : "+v"(p.v0), "+v"(p.v1));
+        const int P = it * 512 + tid;
+        const int tau = P / NP, j = P % NP;
+        const int gg = j & 3, qq = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
+        const float v[8] = {p.v0[0], p.v0[1], p.v0[2], p.v0[3], p.v1[0], p.v1[1], p.v1[2], p.v1[3]};
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            _Float16 a, b;
+            split_f16(v[i] * a_scale, a, b);
+            hi[i] = a; lo[i] = b;
+        }
+        const int row = 4 * gg + 2 * qq + (tau & 1), mt = tau >> 1;
+        const int k8 = chunk * 2 + half, ks = k8 >> 2;
+        const int slot = (k8 & 3) * 16 + row;
+        xs[((0 * MT + mt) * KSTEPS + ks) * 64 + slot] = hi;
+        xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot] = lo;
+    };
+
+    const int strip0 = s0 / kFusedSteps, strip1 = s_end / kFusedSteps;
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) piece_store(it, piece_load(strip0, it));
+
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
+    asm volatile("" ::"v"(bhn));
+    __syncthreads();
+    if (s0 > 0) {   // resume: h of scan step s0 - 1 from the output, and its fp16 image (as k_rec_mfma)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float h = *(op[q] - ostride);
+            hprev[q] = h;
+            _Float16 hi, lo;
+            split_f16(h * kActScale, hi, lo);
+            unsigned char *img = hbuf + (s0 & 1) * kHBufBytes + wr_off;
+            *reinterpret_cast<_Float16 *>(img + (2 * q) * 16) = hi;
+            *reinterpret_cast<_Float16 *>(img + (2 * q + 1) * 16) = lo;
+        }
+        __syncthreads();
+    }
+
+    const half8 *wp = wihfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
+
+    for (int strip = strip0; strip < strip1; ++strip) {
+        // ================= projection phase: gi of this strip into acc (k_gi_gemm inner loop, this direction only)
+        floatx4 acc[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        {
+            // (one register set for the W_ih fragments: the unfused GEMM double-buffers them, here W_hh's 96 registers
+            // and the strip's 48 accumulators leave no room -- the SIMD's other wave covers the L2 round trip)
+            half8 bh[3], bl[3];
+#pragma unroll 1
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    bh[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 0) * 64];
+                    bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
+                    const half8 al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], gi_scale, bv[nt]);
+        __syncthreads();      // every wave has read its A fragments: the image may be overwritten from here on
+
+        // ================= recurrence phase: 8 steps on the strip's gi; the next strip's activations arrive under them
+        // (branch-free on purpose: behind a conditional request hipcc's waitcnt pass falls back to vmcnt(0) at the store --
+        // one HBM round trip per step.  After the last strip the current one is staged again, into an image nobody reads.)
+        const int nstrip = strip + 1 < strip1 ? strip + 1 : strip;
+        Piece pc[NPIECE];
+#pragma unroll
+        for (int j = 0; j < kFusedSteps; ++j) {
+            const int step = strip * kFusedSteps + j;
+            const int cur = (step & 1) * kHBufBytes;
+            const int nxt = kHBufBytes - cur;
+            constexpr int kIssue = NPIECE == 4 ? 1 : 2;      // a piece is requested every kIssue steps, stored 2 steps later
+            half8 a[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const half8 *>(hbuf + cur + ks * kHKStride + rd_off);
+            floatx4 ar = floatx4{0.f, 0.f, 0.f, 0.f}, az = ar, anh = ar, anl = ar;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    ar = mfma16(a[ks], wf[ks][0][sp], ar);
+                    az = mfma16(a[ks], wf[ks][1][sp], az);
+                }
+            }
+            if (j % kIssue == 0 && j / kIssue < NPIECE) pc[j / kIssue] = piece_load(nstrip, j / kIssue);
+            // deferred store of the previous step's h (rec_mfma.hpp DS), unconditional: the first step of a launch writes its
+            // incoming state (zero, or the resumed h) into its OWN slot, which the next step's store then overwrites
+            const long back = step > s0 ? ostride : 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(op[q] - back) = hprev[q];
+            // the piece requested two steps ago has arrived by now: split it and put it into the image (under the MFMAs)
+            if (j >= 2 && (j - 2) % kIssue == 0 && (j - 2) / kIssue < NPIECE) piece_store((j - 2) / kIssue, pc[(j - 2) / kIssue]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                anh = mfma16(a[ks], wf[ks][2][0], anh);
+                anl = mfma16(a[ks], wf[ks][2][1], anl);
+            }
+            float rr[2], zz[2], gnv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * q + (j & 1);
+                const float gr = acc[j >> 1][0][r], gz = acc[j >> 1][1][r];
+                gnv[q] = acc[j >> 1][2][r];
+                const float tr = gr + (ar[2 * q] + ar[2 * q + 1]);
+                const float tz = gz + (az[2 * q] + az[2 * q + 1]);
+                rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
+                zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float hn[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
+                const float e = __builtin_amdgcn_exp2f(an * c_tanh);
+                const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+                const float h = __builtin_fmaf(zz[q], hprev[q] - n, n);
+                hprev[q] = h;
+                hn[q] = h;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                _Float16 hi, lo;
+                split_f16(hn[q] * kActScale, hi, lo);
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                op[q] += ostride;
+            }
+            lds_barrier();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(op[q] - ostride) = hprev[q];      // the last step's h
+}
+
+}  // namespace mdk

@@ -164,3 +164,100 @@ def synth_rl_state(lstm_size=384, cnn_size=128, use_dwells=True, bidirectional=F
     st["linear.weight"] = uni((5, (2 if bidirectional else 1) * H), H) * np.float32(head_gain)
     st["linear.bias"] = uni((5,), H)
     return st
+
+
+# ---- structured pileups: what real drafts contain and i.i.d. sequence does not --------------------------------
+STRUCTURED_KINDS = ("zero_run", "homopolymer", "dinucleotide", "tandem", "depth_cliff", "all_minor")
+
+
+def _emit_columns(rng, true_base, depth_pos, n_cols, p_sub=0.01, p_del=0.01, p_ins=0.01):
+    """One window from a per-position truth: major column per position (+ a minor column where a read inserts),
+    counts / depth of the parent major column, channel order ``a c g t A C G T d D`` as `counts_windows`.
+    depth 0 gives all-zero columns (counts / max(1, depth), features.py:907-911)."""
+    n_pos = len(true_base)
+    out = np.zeros((n_cols, NUM_FEATURES), dtype=np.float32)
+    labels = np.zeros(n_cols, dtype=np.int64)
+    n_ins = rng.binomial(depth_pos, p_ins)
+    n_per_pos = 1 + (n_ins > 0).astype(np.int64)
+    start = np.cumsum(n_per_pos) - n_per_pos
+    keep = start < n_cols
+    cols = start[keep]
+    n_fwd = rng.binomial(depth_pos, 0.5)
+    for strand, n_reads in ((1, n_fwd), (0, depth_pos - n_fwd)):
+        n_d = rng.binomial(n_reads, p_del)
+        n_s = rng.binomial(n_reads - n_d, p_sub)
+        sub_base = (true_base + rng.integers(1, 4, n_pos)) % 4
+        np.add.at(out, (cols, 4 * strand + true_base[keep]), (n_reads - n_d - n_s)[keep])
+        np.add.at(out, (cols, 4 * strand + sub_base[keep]), n_s[keep])
+        np.add.at(out, (cols, 8 + strand), n_d[keep])
+    labels[cols] = np.where(depth_pos[keep] > 0, 1 + true_base[keep], 0)
+    mk = keep & (n_ins > 0) & (start + 1 < n_cols)
+    ins_base = rng.integers(0, 4, n_pos)
+    ins_fwd = rng.binomial(n_ins, 0.5)
+    mcols = start[mk] + 1
+    np.add.at(out, (mcols, 4 + ins_base[mk]), ins_fwd[mk])
+    np.add.at(out, (mcols, ins_base[mk]), (n_ins - ins_fwd)[mk])
+    col_depth = np.ones(n_cols, dtype=np.float32)
+    col_depth[cols] = np.maximum(depth_pos[keep], 1)
+    col_depth[mcols] = np.maximum(depth_pos[mk], 1)
+    out /= col_depth[:, None]
+    return out, labels
+
+
+def structured_windows(kind, n_windows, n_cols, depth=50, seed=1234, return_labels=False):
+    """Windows with the long-range structure of real pileups (the i.i.d. `counts_windows` has none):
+
+      zero_run     a run of >= 2000 zero-coverage columns (all-zero features: the network runs on its biases alone)
+      homopolymer  runs of one base, 5-60 long
+      dinucleotide long two-base repeats (hundreds of columns), short random spacers
+      tandem       a 3-12 base unit repeated for hundreds of columns
+      depth_cliff  coverage jumping between 5x and 500x every few hundred columns
+      all_minor    every column an insertion column: only the inserting reads counted, divided by the full depth
+    """
+    if kind not in STRUCTURED_KINDS:
+        raise ValueError(f"unknown kind {kind!r} (one of {STRUCTURED_KINDS})")
+    rng = np.random.default_rng([seed, STRUCTURED_KINDS.index(kind)])
+    out = np.zeros((n_windows, n_cols, NUM_FEATURES), dtype=np.float32)
+    labels = np.zeros((n_windows, n_cols), dtype=np.int64)
+    for w in range(n_windows):
+        n_pos = n_cols
+        depth_pos = np.maximum(rng.poisson(depth, n_pos), 1)
+        base = rng.integers(0, 4, n_pos)
+        if kind == "zero_run":
+            run = min(n_pos, int(rng.integers(2000, 3001))) if n_pos > 2000 else max(1, n_pos // 2)
+            at = int(rng.integers(0, n_pos - run + 1))
+            depth_pos[at:at + run] = 0
+        elif kind == "homopolymer":
+            i = 0
+            while i < n_pos:
+                run = int(rng.integers(5, 61))
+                base[i:i + run] = rng.integers(0, 4)
+                i += run
+        elif kind in ("dinucleotide", "tandem"):
+            i = 0
+            while i < n_pos:
+                unit = rng.integers(0, 4, 2 if kind == "dinucleotide" else int(rng.integers(3, 13)))
+                if kind == "dinucleotide" and unit[0] == unit[1]:
+                    unit[1] = (unit[1] + 1) % 4
+                run = int(rng.integers(200, 901))
+                base[i:i + run] = np.resize(unit, run)[:max(0, min(run, n_pos - i))]
+                i += run + int(rng.integers(0, 20))
+        elif kind == "depth_cliff":
+            i, deep = 0, bool(rng.integers(0, 2))
+            while i < n_pos:
+                run = int(rng.integers(300, 1101))
+                depth_pos[i:i + run] = np.maximum(rng.poisson(500 if deep else 5, len(depth_pos[i:i + run])), 1)
+                i, deep = i + run, not deep
+        if kind == "all_minor":
+            # insertion columns only: a few of `depth` reads carry a base there
+            n_ins = rng.binomial(depth_pos, 0.08)
+            ins_fwd = rng.binomial(n_ins, 0.5)
+            cols = np.arange(n_cols)
+            np.add.at(out[w], (cols, 4 + base), ins_fwd)
+            np.add.at(out[w], (cols, base), n_ins - ins_fwd)
+            out[w] /= depth_pos[:, None].astype(np.float32)
+            continue
+        out[w], labels[w] = _emit_columns(rng, base, depth_pos, n_cols)
+    if return_labels:
+        return out, labels
+    return out

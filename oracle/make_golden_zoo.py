@@ -1,0 +1,115 @@
+"""Weight zoo: further trained weight sets for the consensus GRU, produced by the UNMODIFIED reference's own training
+step (`TorchModel.process_batch`, medaka/models.py:315-345; RMSprop lr 1e-3 as medaka/training.py:125-133; logits
+during training as medaka/torch_ext.py:300) on the synthetic tasks of oracle/zoo_tasks.py.  Build container only:
+
+    python oracle/make_golden_zoo.py train <name>    (one process per set, ~1-2 h each on one core: the PyTorch-CPU GRU
+                                                      backward is a Python-speed loop over columns) -> oracle/_zoo_parts/
+    python oracle/make_golden_zoo.py merge           -> tests/golden/weights_zoo.npz, tests/golden/zoo_outputs.npz
+
+Why: every real model archive under medaka/data/ is an LFS stub here, and rounds 1-3 rested on ONE trained set that
+learned a memory-free majority vote.  The split scan's margin and certificate (medaka_amd/csrc/scan_split.hpp) are
+claims about how far back a model remembers, so they are now checked on models trained -- 15 to 30 times longer, from
+different seeds -- on tasks that need no memory (majority), memory of a run (homopolymer), and a latched bit carried
+for hundreds of columns (latch).  `zoo_outputs.npz` holds the unmodified reference's `predict_on_batch` for each set
+on windows of its own task (`zoo_input`), the parity anchor of the GPU tests.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim, oracle, zoo_tasks  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+#        name        task           init seed  steps  columns per training window
+ZOO = {"maj1":      ("majority",    1,         2500,  300),
+       "maj2":      ("majority",    2,         4000,  300),
+       "depthmix":  ("depthmix",    3,         2500,  400),
+       "hp":        ("homopolymer", 4,         3000,  300),
+       "latch":     ("latch",       5,         2000,  1000),
+       "latch2":    ("latch",       6,         2500,  800)}
+
+
+def zoo_input(name, n_windows=2, n_cols=3000):
+    """Evaluation windows of a zoo set's own task (seeded: regenerated wherever they are needed, never stored)."""
+    task = ZOO[name][0]
+    return zoo_tasks.make_pool(task, n_windows, n_cols, seed=9000 + ZOO[name][1])[0]
+
+
+def train(name, log=print):
+    arch, models, te = ref_shim.reference_modules()
+    task, seed, steps, T = ZOO[name]
+    torch.manual_seed(seed)
+    model = arch.GRUModel(num_features=10, num_classes=5, gru_size=128)
+    model.train()
+    model.normalise = False
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-3)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    rng = np.random.default_rng(seed)
+    pool_x, pool_y = zoo_tasks.make_pool(task, 768, T, seed=seed)
+    t0 = time.time()
+    acc = 0.0
+    for step in range(steps):
+        if step == steps * 3 // 4:
+            for g in opt.param_groups:
+                g["lr"] = 2.5e-4
+        idx = rng.integers(0, len(pool_x), 32)
+        batch = te.Batch(counts_matrix=torch.from_numpy(pool_x[idx]), labels=torch.from_numpy(pool_y[idx]))
+        opt.zero_grad()
+        loss, metrics = model.process_batch(batch, loss_fn)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        acc = 0.98 * acc + 0.02 * metrics["n_model_correct"] / metrics["n_positions"]
+        if step % 250 == 0 or step == steps - 1:
+            log(f"[{name}] step {step} loss {loss.item():.4f} acc~{acc:.4f} ({time.time() - t0:.0f}s)")
+    model.normalise = True
+    model.eval()
+    # held-out accuracy on fresh windows of the task
+    hx, hy = zoo_tasks.make_pool(task, 16, max(T, 2000), seed=7000 + seed)
+    with torch.inference_mode():
+        p = model.predict_on_batch(te.Batch(counts_matrix=torch.from_numpy(hx))).numpy()
+    held = float((p.argmax(-1) == hy).mean())
+    log(f"[{name}] held-out accuracy {held:.4f}, median max-prob {float(np.median(p.max(-1))):.4f}")
+    out = model.predict_on_batch(te.Batch(counts_matrix=torch.from_numpy(zoo_input(name)))).numpy()
+    return oracle.state_to_numpy(model.state_dict()), out, held
+
+
+PARTS = os.path.join(ROOT, "oracle", "_zoo_parts")
+
+
+def main(argv):
+    if argv[:1] == ["train"]:
+        torch.set_num_threads(max(1, int(os.environ.get("ZOO_THREADS", "1"))))
+        os.makedirs(PARTS, exist_ok=True)
+        for name in argv[1:]:
+            logf = open(os.path.join(PARTS, name + ".log"), "w")
+
+            def log(msg):
+                print(msg, flush=True)
+                logf.write(msg + "\n")
+                logf.flush()
+            st, out, held = train(name, log)
+            np.savez(os.path.join(PARTS, name + ".npz"), out=out, held=np.float32(held), **{"w/" + k: v for k, v in st.items()})
+    elif argv[:1] == ["merge"]:
+        weights, outs = {}, {}
+        for name in ZOO:
+            d = np.load(os.path.join(PARTS, name + ".npz"))
+            weights.update({f"{name}/{k[2:]}": d[k] for k in d.files if k.startswith("w/")})
+            outs[name] = d["out"]
+            outs[name + "/held_out_accuracy"] = d["held"]
+        np.savez(os.path.join(GOLD, "weights_zoo.npz"), **weights)
+        np.savez_compressed(os.path.join(GOLD, "zoo_outputs.npz"), **outs)
+        for name in ZOO:
+            print(name, ZOO[name], "held-out accuracy", float(outs[name + "/held_out_accuracy"]))
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -266,6 +266,56 @@ def test_multi_pass_with_overlap_agrees_bitwise(gold):
     e.close()
 
 
+@pytest.mark.parametrize("bidirectional", [True, False], ids=["bi", "uni"])
+def test_fused_projection_agrees_bitwise(gold, bidirectional):
+    """Option "fuse_proj" (rec_fused.hpp): layers >= 1 compute their input projection inside the recurrence kernel,
+    strip by strip -- the same MFMAs in the same order on the same operands as k_gi_gemm, the same fmaf for scale and
+    bias, the same gate arithmetic -- so the probabilities are BIT-IDENTICAL to the GEMM + recurrence pair, whole
+    layers and resumed (chunked) ones alike.  Every parity result of the unfused path therefore carries over."""
+    if bidirectional:
+        st, kw = weight_set(gold, "trained"), {}
+    else:       # 2 x uni-directional: K = 128 (the KSTEPS = 4 instantiation); weights drawn like PyTorch's default init
+        rng = np.random.default_rng(5)
+        k = 1.0 / np.sqrt(128)
+        st = {}
+        for layer, kin in ((0, 10), (1, 128)):
+            st[f"gru.weight_ih_l{layer}"] = rng.uniform(-k, k, (384, kin)).astype(np.float32)
+            st[f"gru.weight_hh_l{layer}"] = rng.uniform(-k, k, (384, 128)).astype(np.float32)
+            st[f"gru.bias_ih_l{layer}"] = rng.uniform(-k, k, 384).astype(np.float32)
+            st[f"gru.bias_hh_l{layer}"] = rng.uniform(-k, k, 384).astype(np.float32)
+        st["linear.weight"] = rng.uniform(-k, k, (5, 128)).astype(np.float32) * 8
+        st["linear.bias"] = rng.uniform(-k, k, 5).astype(np.float32)
+        kw = dict(bidirectional=False)
+    e = engine.GruEngine(st, **kw)
+    e.enable_timing(True)
+    e.set_option("rec_windows_per_tile", 8)          # the fused kernel carries 8 windows per work-group
+    n = 0
+    for B, T in ((13, 2304), (9, 8), (8, 16), (3, 1000), (40, 264), (17, 4096), (5, 999)):
+        x = synth.counts_windows(B, T, depth=40, seed=B * 1000 + T)
+        outs = {}
+        for fp in (0, 2):
+            e.set_option("fuse_proj", fp)
+            outs[fp] = e.forward_host(x)             # host entry: with T >= 2048 the last layer runs in resumed pieces
+            fused = e.timing()["fused_layers"]
+            assert fused == ((2 if T % 8 == 0 else 0) if fp else 0), (B, T, fp, fused)
+        n += bool(fused)
+        assert np.array_equal(outs[0], outs[2]), (B, T, float(np.abs(outs[0] - outs[2]).max()))
+        if bidirectional:
+            _check(outs[2], oracle.c_gru_forward(x, st) if B * T < 40000 else outs[0], what=f"fused {B}x{T}")
+    assert n >= 5
+    # auto mode: small batches leave CUs idle and keep the GEMM on the side stream; batches that fill the chip fuse
+    e.set_option("rec_windows_per_tile", 0)
+    e.set_option("fuse_proj", 1)
+    e.forward_host(synth.counts_windows(16, 2304, seed=3))
+    assert e.timing()["fused_layers"] == 0
+    x = synth.counts_windows(960, 264, seed=4)
+    out = e.forward_host(x)
+    assert e.timing()["fused_layers"] == 2
+    e.set_option("fuse_proj", 0)
+    assert np.array_equal(e.forward_host(x), out)
+    e.close()
+
+
 def test_fused_and_unfused_layer0_agree(gold):
     x = synth.counts_windows(9, 400, seed=41)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
