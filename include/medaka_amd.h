@@ -66,6 +66,8 @@ typedef struct {
     float total_ms;       /* first kernel start -> last kernel end (device-resident region) */
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
+    int host_streamed;    /* split calls through mdk_gru_forward: bit 0 = x came in, bit 1 = the probabilities left in column
+                             slabs under the recurrences (page-locked buffers); 0 = one copy before / after the forward */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
                              "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both) */
 } mdk_gru_timing;
@@ -85,9 +87,9 @@ typedef struct {
     int fallbacks;    /* rejected certificates since the model was created (each cost one repeated forward) */
     int audited;      /* 1: this call was also run as the sequential scan and the two results compared in full */
     float audit_max_dp; /* largest |p_split - p_sequential| of that comparison */
-    int spot_audits;    /* standing spot audits completed since the model was created ("scan_split_spot") */
-    int spot_failures;  /* ... of which found a difference above the audit tolerance (the split is then turned off) */
-    float spot_max_dp;  /* largest |p_split - p_sequential| any spot audit has seen */
+    int audits;           /* audited calls since the model was created (first calls + every "scan_split_audit_every"-th) */
+    int audit_failures;   /* ... of which found a difference above the audit tolerance (the split is then turned off) */
+    float audit_worst_dp; /* largest |p_split - p_sequential| any audit has seen */
 } mdk_gru_split;
 
 /*
@@ -163,17 +165,14 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   the sequential scan to ~1e-7 (not bit for bit) and depend, at that
  *                                                   level, on B and on the margin the model has escalated to.
  *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
- *                                                   it escalates to -- is also run as the sequential scan and the two
+ *                                                   it escalates to, and every "scan_split_audit_every"-th after that -- is
+ *                                                   also run as the sequential scan and the two
  *                                                   results are compared in full (4e-6; half precision 4e-4); a mismatch
  *                                                   delivers the sequential result and turns the split off.  One extra
  *                                                   forward per model.  2: every certified call (debug), 0: never
- *   "scan_split_spot"      = 1 | 0                  standing spot audit: after a certified call 4 of its windows (rotating) are
- *                                                   recomputed as the sequential scan by a shadow engine on a low-priority
- *                                                   stream of its own, under the caller's next forwards (one audit in flight
- *                                                   at a time), and compared with what was delivered (4e-6 / 4e-4): a
- *                                                   mismatch turns the split off for the model and is reported on stderr and
- *                                                   in mdk_gru_split.spot_failures.  Costs two small device copies per
- *                                                   audited call and ~0.7 GB of workspace
+ *   "scan_split_audit_every" = 256 | n >= 0         standing audit: with "scan_split_audit" = 1, every n-th certified call after
+ *                                                   the first is audited the same way (0: only the first of every margin);
+ *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
@@ -193,9 +192,6 @@ int mdk_gru_get_timing(mdk_gru *m, mdk_gru_timing *out);
 
 /* Chunks, margin and certificate of the last forward (see "scan_split"). */
 int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out);
-/* Waits for the standing spot audit in flight, if any ("scan_split_spot"), and folds its result into the spot_* fields
- * that mdk_gru_get_split reports (normally the next forward does that when it finds the audit finished). */
-int mdk_gru_spot_wait(mdk_gru *m);
 
 /* The shape arithmetic of "scan_split" on its own (no device needed): how a batch of B windows of T columns would be
  * split by a process that is one of `gpu_share` on its GPU, with option values `scan_split` (1 auto, n >= 2 forced) and
@@ -257,10 +253,11 @@ int mdk_rl_create(const mdk_rl_desc *desc, const float *const *weights, int n_we
 int mdk_rl_forward(mdk_rl *m, const unsigned char *x_host, int B, int P, int D, int F, float *probs_host);
 /* Device-resident variant, enqueued on `stream`.  lstm_size 128: asynchronous.  lstm_size 384 (rl_lstm384): the
  * cluster recurrence verifies its cross-CU exchange, so by default the call SYNCHRONISES `stream`, and after a
- * time-out (a late cluster member: the path wants 192 CUs of the GPU to itself) re-runs once on the plain
- * schedule before failing with MDK_ERR_DEVICE.  A GPU that cannot host the kernel (fewer than 192 free CUs) is
- * detected by the clusters' placement handshake, bounded at 50 ms of wall clock per try: the error comes back
- * within ~0.1 s, not after seconds of spinning.  Option "wide_async" = 1 makes it asynchronous (no retry);
+ * time-out (a late cluster member: the path wants 192 CUs of the GPU to itself) re-runs on the plain schedule.
+ * Every try is bounded on the device (the clusters' placement handshake: 50 ms of wall clock); the host retries with
+ * a growing pause (20 ... 320 ms) until the forward goes through or "wide_wait_ms" (default 3000) are spent, and only
+ * then fails with MDK_ERR_DEVICE: a co-tenant that holds CUs for a few hundred milliseconds is waited out, a GPU that
+ * cannot host the kernel is reported after the budget.  Option "wide_async" = 1 makes it asynchronous (no retry);
  * mdk_rl_check() then reports a time-out of any earlier forward. */
 int mdk_rl_forward_dev(mdk_rl *m, const unsigned char *x_dev, int B, int P, int D, int F, float *probs_dev,
                        void *stream);
@@ -270,7 +267,7 @@ int mdk_rl_check(mdk_rl *m, void *stream);
 typedef struct {
     float front_ms;      /* k_rl_front */
     float total_ms;      /* whole forward on the stream */
-    int wide_retries;    /* lstm_size 384: forwards re-run on the plain schedule after an exchange time-out */
+    int wide_retries;    /* lstm_size 384: tries re-run on the plain schedule after an exchange time-out (cumulative) */
 } mdk_rl_timing;
 int mdk_rl_enable_timing(mdk_rl *m, int on);
 int mdk_rl_get_timing(mdk_rl *m, mdk_rl_timing *out);
@@ -281,6 +278,9 @@ int mdk_rl_set_normalise(mdk_rl *m, int normalise);
  *   "wide_async"           = 0 | 1                  lstm_size 384: do not synchronise in mdk_rl_forward_dev (see above)
  *   "overlap_gemm"         = 1 | 0                  lstm_size 384: next layer's projection on a side stream
  *                                                   behind resumable recurrence chunks (P >= 1024)
+ *   "wide_wait_ms"         = 3000 | 0..60000        lstm_size 384: wall-clock budget of the host's retries after a
+ *                                                   cluster time-out (0: the second time-out is the error)
+ *   "wide_inject_timeout"  = n                      test hook: the next n tries find the time-out flag already raised
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through
  *                                                   granules, even when a cluster shares one XCD
  *   "wide_groups_per_cluster" = 0 (auto) | 1 | 2     lstm_size 384: 8-window groups interleaved per cluster

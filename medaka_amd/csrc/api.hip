@@ -104,23 +104,12 @@ struct mdk_gru {
     int split_audited_key = 0;               // margin | precision << 16 whose first certified call has been audited (0 = none yet)
     float *audit = nullptr;                  // the sequential scan's probabilities of an audited call
     size_t audit_cap = 0;
-    // standing spot audit of certified split calls (run_forward / spot_submit): a shadow engine on the same weights
-    // re-runs a few windows of a certified call as the SEQUENTIAL scan on its own low-priority stream, under the
-    // caller's next forwards, and the two results are compared when it has finished
-    std::vector<std::vector<float>> host_weights;   // what mdk_gru_create was given (the shadow is created from it)
-    mdk_gru *shadow = nullptr;
-    int opt_split_spot = 1;                  // 0 off, 1 on (one audit in flight at a time)
-    hipStream_t spot_stream = nullptr;
-    hipEvent_t spot_ready = nullptr, spot_done = nullptr;
-    bool spot_in_flight = false;
-    float *spot_x = nullptr, *spot_p = nullptr, *spot_q = nullptr;
-    size_t spot_cap = 0;                     // columns the three buffers hold
-    unsigned *spot_flag = nullptr, *spot_host = nullptr;
-    int spot_next = 0, spot_n = 0, spot_precision = 0;
-    long spot_count = 0;
-    int spot_failures = 0;
-    float spot_worst = 0.f;
-    bool is_shadow = false;
+    // standing audit: every `opt_split_audit_every`-th certified call is ALSO run as the sequential scan (run_forward)
+    int opt_split_audit_every = 256;
+    long split_calls_since_audit = 0;
+    long audits_done = 0;
+    int audit_failures = 0;
+    float audit_worst = 0.f;
     // timing
     bool timing = false;
     mdk_gru_timing last{};
@@ -139,14 +128,6 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
     if (m->split_host) (void)hipHostFree(m->split_host);
-    if (m->spot_stream) (void)hipStreamSynchronize(m->spot_stream);
-    if (m->shadow) mdk_gru_destroy(m->shadow);
-    (void)hipSetDevice(m->device);
-    free_dev(m->spot_x); free_dev(m->spot_p); free_dev(m->spot_q); free_dev(m->spot_flag);
-    if (m->spot_host) (void)hipHostFree(m->spot_host);
-    if (m->spot_ready) (void)hipEventDestroy(m->spot_ready);
-    if (m->spot_done) (void)hipEventDestroy(m->spot_done);
-    if (m->spot_stream) (void)hipStreamDestroy(m->spot_stream);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -179,16 +160,6 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->device = device;
     m->D = D;
     m->layers.resize(L);
-    for (int i = 0; i < n_weights; ++i) {       // sizes in the state_dict order of the header
-        size_t n;
-        if (i >= 4 * L * D) n = (i == 4 * L * D) ? (size_t)C * D * H : (size_t)C;
-        else {
-            const int l = i / (4 * D), kind = i % 4;
-            const size_t K = (l == 0) ? I : D * H;
-            n = kind == 0 ? (size_t)kG * K : kind == 1 ? (size_t)kG * kH : (size_t)kG;
-        }
-        m->host_weights.emplace_back(weights[i], weights[i] + n);
-    }
     // process-wide defaults of the split scan (the options of the same names override them per model)
     if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
@@ -389,9 +360,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
-    } else if (!strcmp(key, "scan_split_spot")) {
-        if (value < 0 || value > 1) return fail(MDK_ERR_ARG, "scan_split_spot must be 0 or 1");
-        m->opt_split_spot = value;
+    } else if (!strcmp(key, "scan_split_audit_every")) {
+        if (value < 0) return fail(MDK_ERR_ARG, "scan_split_audit_every must be >= 0 (0 = only the first call of a margin)");
+        m->opt_split_audit_every = value;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
@@ -426,15 +397,7 @@ extern "C" int mdk_gru_get_split(mdk_gru *m, mdk_gru_split *out) {
     return MDK_OK;
 }
 extern "C" int mdk_gru_device(const mdk_gru *m) { return m ? m->device : -1; }
-static int spot_poll(mdk_gru *m, bool wait);
-static void report_spot(mdk_gru *m);
-extern "C" int mdk_gru_spot_wait(mdk_gru *m) {
-    if (!m) return fail(MDK_ERR_ARG, "null model");
-    HIP_TRY(hipSetDevice(m->device));
-    int rc = spot_poll(m, true);
-    report_spot(m);
-    return rc;
-}
+
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -499,7 +462,77 @@ enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
 struct HostIO {
     const float *x_host = nullptr;   // (nb, T, F) of this pass, or null: x is already on the device
     float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
+    // Split calls whose host buffers are page-locked (run_split): the device-visible addresses of the caller's buffers.
+    // x lands in `x_real` -- the real (B, T, F) layout, every column crossing PCIe once -- slab by slab in the order the
+    // chunks' scans need it and is gathered from there into the virtual batch; the probabilities leave from the real
+    // (B, T, C) device result chunk by chunk behind the head.  Both by k_copy_cols, on the copy streams.
+    const float *x_map = nullptr;
+    float *x_real = nullptr;
+    float *p_map = nullptr;
 };
+
+// the streamed host path of a split call cuts the virtual windows' scans into phases (forward_pass): layer 0 fused, and
+// a virtual window long enough for that to be worth the launches
+constexpr int kSplitStreamMinT = 512;
+
+// Device-visible address of a page-locked host buffer (hipHostMalloc / hipHostRegister: torch's pinned allocator,
+// mdk_host_alloc), or null for ordinary pageable memory.
+static void *mapped_ptr(const void *host) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
+// [a, b) minus what `cover` holds is appended to `fresh`; `cover` (sorted, disjoint) then includes [a, b)
+struct ColRange { int a, b; };
+static void claim_range(std::vector<ColRange> &cover, int a, int b, std::vector<ColRange> &fresh) {
+    if (a >= b) return;
+    int cur = a;
+    std::vector<ColRange> merged;
+    bool placed = false;
+    ColRange add{a, b};
+    for (const ColRange &c : cover) {
+        if (c.b <= a || c.a >= b) {                 // disjoint (touching counts as disjoint for the subtraction)
+            if (c.b == a) { add.a = c.a; continue; }
+            if (c.a == b) { add.b = c.b; continue; }
+            if (!placed && c.a > b) { merged.push_back(add); placed = true; }
+            merged.push_back(c);
+            continue;
+        }
+        if (c.a > cur) fresh.push_back({cur, c.a});
+        cur = std::max(cur, c.b);
+        add.a = std::min(add.a, c.a);
+        add.b = std::max(add.b, c.b);
+    }
+    if (cur < b) fresh.push_back({cur, b});
+    if (!placed) merged.push_back(add);
+    std::sort(merged.begin(), merged.end(), [](const ColRange &x, const ColRange &y) { return x.a < y.a; });
+    // `add` may have been placed before growing: rebuild it at its final extent
+    std::vector<ColRange> out;
+    for (const ColRange &c : merged) {
+        if (!out.empty() && c.a <= out.back().b) out.back().b = std::max(out.back().b, c.b);
+        else out.push_back(c);
+    }
+    cover.swap(out);
+}
+
+// ranges of a (B, T, E) array, kMaxCopyRanges per launch
+static void launch_copy_cols(const float *src, float *dst, int B, int T, int E, const std::vector<ColRange> &ranges, hipStream_t st) {
+    const bool vec2 = E % 2 == 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0;
+    for (size_t r0 = 0; r0 < ranges.size(); r0 += kMaxCopyRanges) {
+        CopyPlan pl;
+        pl.n = (int)std::min<size_t>(kMaxCopyRanges, ranges.size() - r0);
+        pl.cum[0] = 0;
+        for (int i = 0; i < pl.n; ++i) { pl.a[i] = ranges[r0 + i].a; pl.cum[i + 1] = pl.cum[i] + (ranges[r0 + i].b - ranges[r0 + i].a); }
+        const long units = (long)pl.cum[pl.n] * E / (vec2 ? 2 : 1) * B;
+        if (units <= 0) continue;
+        const unsigned blocks = (unsigned)std::min<long>((units + 1023) / 1024, 256);
+        if (vec2) hipLaunchKernelGGL(k_copy_cols<2>, dim3(blocks), dim3(256), 0, st, src, dst, B, T, E, pl);
+        else hipLaunchKernelGGL(k_copy_cols<1>, dim3(blocks), dim3(256), 0, st, src, dst, B, T, E, pl);
+    }
+}
 
 static int pool_event(mdk_gru *m, hipEvent_t *out) {
     if (m->ov_next == m->ov_ev.size()) {
@@ -523,6 +556,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     int rc;
     const float *in = x;
     const bool io_in = io && io->x_host, io_out = io && io->p_host;
+    const bool sp_in = sp && io && io->x_map, sp_out = sp && io && io->p_map;     // split call on page-locked host buffers
     const size_t x_bytes = (size_t)M * m->desc.num_features * sizeof(float);
     const size_t p_bytes = (size_t)M * m->desc.num_classes * sizeof(float);
     m->ov_next = 0;
@@ -625,7 +659,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // work-group can share its CUs changed nothing), at B >= 1000 there are no idle CUs and no gain.
     constexpr int kOvMaxWgs = 208;   // profiles/run_overlap_sweep.sh: +10 % at 128 work-groups, +5 % at 160, +-1 % at 200-256
     const bool ablated = (abl != 0 && !hp && nq <= 2);
-    const bool can_chunk = D == 2 && !ablated && T >= 2048 && T % (2 * kGemmSteps) == 0;
+    const bool can_chunk_any = D == 2 && !ablated && T % (2 * kGemmSteps) == 0;
+    const bool can_chunk = can_chunk_any && T >= 2048;
+    const bool can_chunk_sp = can_chunk_any && T >= kSplitStreamMinT;      // (run_split asked split_stream_ok first)
     const bool overlap_ok = m->opt_overlap && can_chunk && L >= 2 &&
                             (n_wg * D * m->opt_gpu_share <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
     // Layers >= 1 in the throughput regime (every CU holds a recurrence work-group: nothing is idle to hide a projection
@@ -636,8 +672,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                            (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && !overlap_ok));
     const bool overlap = overlap_ok && !fuse_proj;
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
-    const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
-    const bool stream_out = io_out && can_chunk && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
+    const bool stream_in = ((io_in && can_chunk) || (sp_in && can_chunk_sp)) && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
+    const bool stream_out = ((io_out && can_chunk) || (sp_out && can_chunk_sp)) && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
+    if ((sp_in && !stream_in) || (sp_out && !stream_out)) return fail(MDK_ERR_ARG, "internal: split host streaming asked for a shape that cannot be chunked");
+    std::vector<ColRange> x_cover;      // real columns of x already landed on the device (split host path)
     const int F = m->desc.num_features, C = m->desc.num_classes;
     // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
     auto copy_in_cols = [&](int t0, int nt) -> int {
@@ -646,6 +684,19 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                                  io->x_host + (size_t)t0 * F, (size_t)T * F * sizeof(float),
                                  (size_t)nt * F * sizeof(float), (size_t)nb, hipMemcpyHostToDevice, m->copy_in));
         return MDK_OK;
+    };
+    // split host path: local columns [t0, t0 + nt) of every chunk = real columns start[k] + [t0, t0 + nt): what has not
+    // crossed PCIe yet comes over (every real column once: neighbouring chunks share their margins), then the slab is
+    // gathered from the real layout into the virtual batch; both on the copy stream
+    auto split_in_cols = [&](int t0, int nt) {
+        if (nt <= 0) return;
+        std::vector<ColRange> fresh;
+        for (int k = 0; k < sp->S; ++k) claim_range(x_cover, sp->start[k] + t0, sp->start[k] + t0 + nt, fresh);
+        launch_copy_cols(io->x_map, io->x_real, sp->B, sp->T, F, fresh, m->copy_in);
+        const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(io->x_real) % 8 == 0) ? 2 : 1;
+        const size_t n = (size_t)nb * nt * F / vec;
+        hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 4)), dim3(256), 0, m->copy_in,
+                           (const float *)io->x_real, const_cast<float *>(x), *sp, F, vec, t0, nt);
     };
     if (io_in && !stream_in)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x), io->x_host, x_bytes, hipMemcpyHostToDevice, s));
@@ -681,7 +732,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         const bool fused_proj = l >= 1 && fuse_proj;
         // device-resident x: the packing of all but the first slab pair runs on the side stream under the
         // first recurrence phases instead of in front of them (0.25 ms of k_pack_x at 200 x 10000)
-        const bool dev_slabs = !io_in && fuse && can_chunk && l == 0 && m->opt_overlap;
+        const bool dev_slabs = !io_in && !sp_in && fuse && can_chunk && l == 0 && m->opt_overlap;
         const bool slabs = (stream_in || dev_slabs) && l == 0;       // this layer's recurrence starts slab by slab
         const bool side_gemm = overlap && l == 0;                  // layer 1's projection behind this layer's chunks
         const bool side_head = (overlap || stream_out) && l == L - 1 && L >= 2;   // classifier head behind the chunks
@@ -811,7 +862,11 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 } else if (slabs && p < n_first) {
                     // columns [rs0, rs0+rns) and their mirror [T-rs0-rns, T-rs0); the last pair is adjacent
                     const int lo = rs0, hi = T - rs0 - rns;
-                    if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
+                    if (sp_in) {
+                        if (lo + rns == hi) split_in_cols(lo, 2 * rns);
+                        else { split_in_cols(lo, rns); split_in_cols(hi, rns); }
+                    }
+                    else if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
                     else { if ((rc = copy_in_cols(lo, rns)) || (rc = copy_in_cols(hi, rns))) return rc; }
                     hipEvent_t ev;
                     if ((rc = pool_event(m, &ev))) return rc;
@@ -880,7 +935,24 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if (!head_done) launch_head(in, s, 0, T);
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
-    if (io_out) {
+    if (sp_out) {
+        // split host path: each head chunk delivered, for chunk k, the real columns core_k /\ (start[k] + [t0, t0 + nt)):
+        // they leave for the caller's page-locked buffer behind the chunk's event, on the copy stream
+        for (const OutRange &r : out_ranges) {
+            std::vector<ColRange> cols;
+            for (int k = 0; k < sp->S; ++k) {
+                const int a = std::max(sp->core0[k], sp->start[k] + r.t0), b = std::min(sp->core0[k + 1], sp->start[k] + r.t0 + r.nt);
+                if (a < b) cols.push_back({a, b});
+            }
+            HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
+            launch_copy_cols(probs, io->p_map, sp->B, sp->T, C, cols, m->copy_out);
+        }
+        hipEvent_t done;
+        if ((rc = pool_event(m, &done))) return rc;
+        HIP_TRY(hipEventRecord(done, m->copy_out));
+        HIP_TRY(hipStreamWaitEvent(s, done, 0));
+        HIP_TRY(hipGetLastError());
+    } else if (io_out) {
         if (out_ranges.empty()) {      // head not chunked, or its chunks were not streamed: one copy behind it
             HIP_TRY(hipMemcpyAsync(io->p_host, probs, p_bytes, hipMemcpyDeviceToHost, s));
         } else {
@@ -1001,6 +1073,10 @@ static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
                             m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass, p);
 }
 
+static bool split_stream_ok(const mdk_gru *m, int Tv) {
+    return m->opt_stream_host && m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && Tv >= kSplitStreamMinT && Tv % (2 * kGemmSteps) == 0;
+}
+
 static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
                      const float *x_host, float *probs_host, bool *certified) {
     const size_t F = m->desc.num_features, C = m->desc.num_classes;
@@ -1021,23 +1097,34 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     // The host buffers cross PCIe whole, as one copy each way, around the device-resident split forward: the time-slab
     // streaming of the sequential host path would have to copy S strided pieces per slab, and strided copies with
     // short rows run at half the rate of a contiguous one (profiles/r3_experiments/scan_split/host_path.txt)
-    if (x_host)
+    // Host buffers.  Page-locked ones (what `predict_on_batch` hands over: medaka_amd.torch_ext's collate buffer in, a pinned
+    // result tensor out; mdk_host_alloc for C callers) are read and written by copy KERNELS through their device-visible
+    // addresses, a slab of columns at a time under the recurrences (forward_pass, HostIO).  Pageable buffers cross PCIe
+    // whole, one copy each way around the device-resident forward: the time-slab DMA copies of the sequential host path
+    // would be S strided pieces per slab at half the PCIe rate (profiles/r3_experiments/scan_split/host_path.txt).
+    const bool can_stream = split_stream_ok(m, sp.Tv);
+    const float *x_map = (can_stream && x_host) ? static_cast<const float *>(mapped_ptr(x_host)) : nullptr;
+    float *p_map = (can_stream && probs_host) ? static_cast<float *>(mapped_ptr(probs_host)) : nullptr;
+    if (x_host && !x_map)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
-    {
+    if (!x_map) {
         // float2 copies need 8-byte aligned rows: an even feature count and a caller's pointer that is not on an odd float
         const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 8 == 0) ? 2 : 1;
         const size_t n = cols * F / vec;
         hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
-                           x_dev, m->xv, sp, (int)F, vec);
+                           x_dev, m->xv, sp, (int)F, vec, 0, sp.Tv);
     }
+    HostIO io;
+    io.x_map = x_map; io.x_real = const_cast<float *>(x_dev); io.p_map = p_map;
+    m->last.host_streamed = (x_map ? 1 : 0) | (p_map ? 2 : 0);
     EvTimer tm{m, s};
-    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, nullptr, &sp);
+    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, (x_map || p_map) ? &io : nullptr, &sp);
     if (rc) return rc;
     hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
                        (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);
     HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipGetLastError());
-    if (probs_host)
+    if (probs_host && !p_map)
         HIP_TRY(hipMemcpyAsync(probs_host, probs_dev, (size_t)sp.B * sp.T * C * sizeof(float), hipMemcpyDeviceToHost, s));
     if ((rc = finish_timing(m, tm, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
@@ -1066,111 +1153,22 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     return MDK_OK;
 }
 
-// ---- standing spot audit ------------------------------------------------------------------------------------------
-// The certificate argues from the states at the junctions and the first-call audit looks at one batch.  This looks at
-// what is delivered, on every kind of input the model meets, for as long as it runs: after a certified call, kSpotWin
-// windows of it (a rotating choice) are copied aside with their split-scan probabilities, a SHADOW engine (same
-// weights, sequential scan, its own small workspace and a stream of its own) recomputes them under the caller's next
-// forwards -- two 4-window work-groups next to the 250 of a split forward -- and the comparison is read when the next
-// call finds it finished.  One audit in flight at a time.  A difference above the audit tolerance cannot take the
-// delivered batch back; it turns the split off for the model, counts in mdk_gru_split.spot_failures and says so on
-// stderr.  Cost: two device-to-device copies of 4 windows per audited call (measured: bench.py `spot_audit`).
-constexpr int kSpotWin = 4;
-
-static int spot_poll(mdk_gru *m, bool wait) {
-    if (!m->spot_in_flight) return MDK_OK;
-    hipError_t e = wait ? hipEventSynchronize(m->spot_done) : hipEventQuery(m->spot_done);
-    if (e == hipErrorNotReady) return MDK_OK;
-    if (e != hipSuccess) return fail(MDK_ERR_DEVICE, "spot audit: %s", hipGetErrorString(e));
-    m->spot_in_flight = false;
-    float dp;
-    memcpy(&dp, &m->spot_host[0], sizeof(float));
-    m->spot_count++;
-    m->spot_worst = std::max(m->spot_worst, dp);
-    if (!(dp <= (m->spot_precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol))) {
-        m->spot_failures++;
-        m->split_disabled = true;
-        fprintf(stderr, "[medaka_amd] split scan: a spot audit found |p_split - p_sequential| = %.3g on %d windows of a "
-                        "CERTIFIED call (tolerance %.1g): the split scan is now off for this model; results delivered "
-                        "before this point may differ from the sequential scan by that much\n",
-                dp, m->spot_n, (double)(m->spot_precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol));
-    }
-    return MDK_OK;
-}
-
-static int spot_submit(mdk_gru *m, const float *x_dev, const float *probs_dev, int B, int T, hipStream_t s) {
-    if (!m->opt_split_spot || m->is_shadow || m->spot_in_flight || m->split_disabled) return MDK_OK;
-    const size_t F = m->desc.num_features, C = m->desc.num_classes;
-    if (!m->shadow) {
-        std::vector<const float *> ptrs;
-        for (auto &w : m->host_weights) ptrs.push_back(w.data());
-        int rc = mdk_gru_create(&m->desc, ptrs.data(), (int)ptrs.size(), m->device, &m->shadow);
-        if (rc) return rc;
-        m->shadow->is_shadow = true;
-        m->shadow->opt_scan_split = 0;
-        m->shadow->opt_overlap = 0;          // (no second gi buffer; 4 windows do not need the side stream)
-        m->shadow->opt_split_spot = 0;
-        std::vector<std::vector<float>>().swap(m->shadow->host_weights);
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = numerically greatest = LOWEST priority
-        HIP_TRY(hipStreamCreateWithPriority(&m->spot_stream, hipStreamNonBlocking, lo));
-        HIP_TRY(hipEventCreateWithFlags(&m->spot_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->spot_done, hipEventDisableTiming));
-        HIP_TRY(hipMalloc((void **)&m->spot_flag, sizeof(unsigned)));
-        HIP_TRY(hipHostMalloc((void **)&m->spot_host, sizeof(unsigned), hipHostMallocDefault));
-    }
-    const int nw = std::min(kSpotWin, B);
-    const int w0 = std::min(m->spot_next % B, B - nw);
-    m->spot_next = (w0 + nw) % B;
-    const size_t cols = (size_t)nw * T;
-    if (cols > m->spot_cap) {
-        free_dev(m->spot_x); free_dev(m->spot_p); free_dev(m->spot_q);
-        m->spot_x = m->spot_p = m->spot_q = nullptr;
-        m->spot_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m->spot_x, cols * F * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&m->spot_p, cols * C * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&m->spot_q, cols * C * sizeof(float)));
-        m->spot_cap = cols;
-    }
-    HIP_TRY(hipMemcpyAsync(m->spot_x, x_dev + (size_t)w0 * T * F, cols * F * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(m->spot_p, probs_dev + (size_t)w0 * T * C, cols * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipEventRecord(m->spot_ready, s));
-    HIP_TRY(hipStreamWaitEvent(m->spot_stream, m->spot_ready, 0));
-    HIP_TRY(hipEventSynchronize(m->spot_ready));     // the caller may reuse x / probs as soon as the call returns
-    mdk_gru *sh = m->shadow;
-    sh->precision = m->precision;
-    sh->desc.normalise = m->desc.normalise;
-    int rc = run_passes(sh, m->spot_x, nw, T, m->spot_q, m->spot_stream, nullptr, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(m->spot_flag, 0, sizeof(unsigned), m->spot_stream));
-    hipLaunchKernelGGL(k_split_audit, dim3((unsigned)std::min<size_t>((cols * C + 255) / 256, 256)), dim3(256), 0, m->spot_stream,
-                       (const float *)m->spot_p, (const float *)m->spot_q, cols * C, m->spot_flag);
-    HIP_TRY(hipMemcpyAsync(m->spot_host, m->spot_flag, sizeof(unsigned), hipMemcpyDeviceToHost, m->spot_stream));
-    HIP_TRY(hipEventRecord(m->spot_done, m->spot_stream));
-    HIP_TRY(hipGetLastError());
-    m->spot_in_flight = true;
-    m->spot_n = nw;
-    m->spot_precision = m->precision;
-    return MDK_OK;
-}
-
-static void report_spot(mdk_gru *m) {
-    m->last_split.spot_audits = (int)std::min<long>(m->spot_count, 0x7fffffff);
-    m->last_split.spot_failures = m->spot_failures;
-    m->last_split.spot_max_dp = m->spot_worst;
+static void report_audits(mdk_gru *m) {
+    m->last_split.audits = (int)std::min<long>(m->audits_done, 0x7fffffff);
+    m->last_split.audit_failures = m->audit_failures;
+    m->last_split.audit_worst_dp = m->audit_worst;
 }
 
 // one call: split scan when the shape is latency-bound and the certificate holds, the sequential passes otherwise
 static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
                        const float *x_host, float *probs_host) {
     SplitPlan sp;
-    int rc = spot_poll(m, false);
-    if (rc) return rc;
+    int rc;
     const int fallbacks = m->last_split.fallbacks;
     memset(&m->last_split, 0, sizeof(m->last_split));
     m->last_split.chunks = 1; m->last_split.columns = T; m->last_split.fallbacks = fallbacks;
     m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
-    report_spot(m);
+    report_audits(m);
 #ifdef MDK_DEBUG_HOOKS
     static const bool keep = getenv("MDK_SPLIT_KEEP") != nullptr;   // debug builds only: deliver a rejected split as it is
 #else
@@ -1180,15 +1178,21 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         bool ok = false;
         rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
         if (rc) return rc;
-        report_spot(m);
+        report_audits(m);
         if (keep) return MDK_OK;
         if (ok) {
-            // Audit: the first certified call of a model (and the first at every margin / precision it moves to) is ALSO run as
-            // the sequential scan, and the two results are compared in full -- the certificate argues from the states
-            // at the junctions, the audit looks at what is delivered.  One extra forward per model, not per call.
+            // Audit.  The certificate argues from the states at the junctions; the audit looks at what is delivered: the call is
+            // ALSO run as the sequential scan on the device and the two (B, T, C) results are compared in full.  Audited are the
+            // first certified call of a model (and the first at every margin / precision it moves to) and, as a STANDING check on
+            // whatever input the model meets later, every `scan_split_audit_every`-th certified call after that (default 256:
+            // one sequential forward of ~2x a split forward's time per 256 calls, < 1 %; a concurrent low-priority audit was
+            // tried first and cost far more -- any second tenant keeps the recurrence's work-groups from being resident
+            // together).  A mismatch delivers the sequential result and turns the split off for the model.
             const int audit_key = sp.G | (m->precision << 16) | (1 << 24);
-            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && m->split_audited_key == audit_key))
-                return spot_submit(m, x_dev, probs_dev, B, T, s);
+            const bool first = m->split_audited_key != audit_key;
+            const bool periodic = !first && m->opt_split_audit_every > 0 && ++m->split_calls_since_audit >= m->opt_split_audit_every;
+            if (m->opt_split_audit == 0 || (m->opt_split_audit == 1 && !first && !periodic)) return MDK_OK;
+            m->split_calls_since_audit = 0;
             const size_t n = (size_t)B * T * m->desc.num_classes;
             if (n > m->audit_cap) {
                 free_dev(m->audit); m->audit = nullptr; m->audit_cap = 0;
@@ -1205,19 +1209,25 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
             HIP_TRY(hipStreamSynchronize(s));
             float dp;
             memcpy(&dp, &m->split_host[0], sizeof(float));
+            m->audits_done++;
+            m->audit_worst = std::max(m->audit_worst, dp);
             m->last_split = certified;
             m->last_split.audited = 1;
             m->last_split.audit_max_dp = dp;
             if (dp <= (m->precision == MDK_PREC_FP16 ? kAuditTolHalf : kAuditTol)) {
                 m->split_audited_key = audit_key;
+                report_audits(m);
                 return MDK_OK;
             }
             // never seen: certified junctions, different probabilities.  The sequential result is already there.
-            fprintf(stderr, "[medaka_amd] split scan: the first-call audit found |p_split - p_sequential| = %.3g behind a certified "
-                            "split (margin %d): the sequential result is delivered and the split scan is off for this model\n", dp, sp.G);
+            fprintf(stderr, "[medaka_amd] split scan: an audit found |p_split - p_sequential| = %.3g behind a certified split (margin %d, "
+                            "%s call): the sequential result is delivered and the split scan is off for this model\n", dp, sp.G,
+                    first ? "first" : "a later");
+            m->audit_failures++;
             m->last_split.status = MDK_SPLIT_REJECTED;
             m->last_split.fallbacks++;
             m->split_disabled = true;
+            report_audits(m);
             HIP_TRY(hipMemcpyAsync(probs_dev, m->audit, n * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (probs_host) HIP_TRY(hipMemcpyAsync(probs_host, m->audit, n * sizeof(float), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -1242,7 +1252,7 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
                 m->last_split.max_delta, sp.G, next);
     }
     rc = run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
-    report_spot(m);
+    report_audits(m);
     return rc;
 }
 

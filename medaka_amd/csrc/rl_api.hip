@@ -3,6 +3,9 @@
 // MFMA recurrence / projection kernels as the GRU model (CELL = 1, four gate tiles) -> head.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <thread>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -57,6 +60,8 @@ struct mdk_rl {
     int opt_async = 0;           // wide model: 1 = mdk_rl_forward_dev does not synchronise (no retry; see mdk_rl_check)
     int n_cus = 0;
     int wide_retries = 0;        // forwards that were re-run on the plain schedule after a time-out
+    int opt_wait_ms = 3000;      // wide model: wall-clock budget of the host's retries after a time-out ("wide_wait_ms")
+    int inject_timeouts = 0;     // test hook ("wide_inject_timeout"): the next n tries find the device flag already up
     bool timing = false;         // hipEvent timing of the front end and of the whole forward (adds a sync)
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // forward start, front start, front end, forward end
     mdk_rl_timing last{};
@@ -404,6 +409,12 @@ extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
         m->opt_async = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value ? 1 : 0;
+    } else if (!strcmp(key, "wide_wait_ms")) {
+        if (value < 0 || value > 60000) return fail(MDK_ERR_ARG, "wide_wait_ms must be 0..60000");
+        m->opt_wait_ms = value;
+    } else if (!strcmp(key, "wide_inject_timeout")) {
+        if (value < 0 || value > 1000) return fail(MDK_ERR_ARG, "wide_inject_timeout must be 0..1000");
+        m->inject_timeouts = value;
     } else if (!strcmp(key, "wide_write_through")) {
         m->opt_force_wt = value ? 1 : 0;
     } else if (!strcmp(key, "wide_poll_delay")) {
@@ -593,20 +604,44 @@ static int rl_forward_wide_once(mdk_rl *m, const unsigned char *x_dev, int B, in
 // The cluster exchange needs every member of a cluster on a CU at the same time.  A time-out (a late
 // member: another tenant on the GPU, or the side-stream projection competing for CUs) is not an error
 // yet: the layer stack is run once more on the plain schedule -- nothing on the side stream, one launch
-// per layer -- and only a second time-out is reported.
+// per layer.  If that times out as well somebody else is holding CUs: every try is bounded on the device (50 ms of
+// wall clock in the placement handshake, every later launch of a lost forward returns at once), so the HOST keeps
+// retrying the plain schedule with a growing pause -- 20, 40, ... 320 ms -- until the forward goes through or
+// "wide_wait_ms" (3 s by default) of wall clock are spent; only then MDK_ERR_DEVICE.  A co-tenant or a long foreign
+// kernel that holds the CUs for a few hundred milliseconds is waited out; a GPU that cannot host the kernel at all
+// is reported after the budget, not after minutes of spinning and never with a wrong result.
 static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
                            float *probs_dev, hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto inject = [&]() -> int {          // test hook: raise the device flag before the try, as a lost forward would have
+        if (m->inject_timeouts <= 0 || !m->status) return MDK_OK;
+        m->inject_timeouts--;
+        const int one = 1;
+        HIP_TRY(hipMemcpyAsync(m->status, &one, sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return MDK_OK;
+    };
     int timed_out = 0;
-    int rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, true, &timed_out);
-    if (rc || !timed_out) return rc;
-    m->wide_retries++;
-    rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, false, &timed_out);
+    int rc = inject();
     if (rc) return rc;
-    if (timed_out)
-        return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out twice (the second time without the "
-                                    "overlapped projection): the rl_lstm384 path needs %d CUs of the GPU to itself",
-                    8 * kWC * 2);
-    return MDK_OK;
+    rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, true, &timed_out);
+    if (rc || !timed_out) return rc;
+    int pause_ms = 0, tries = 1;
+    for (;;) {
+        m->wide_retries++;
+        tries++;
+        if ((rc = inject())) return rc;
+        timed_out = 0;
+        rc = rl_forward_wide_once(m, x_dev, B, P, Dp, F, probs_dev, s, false, &timed_out);
+        if (rc || !timed_out) return rc;
+        const long spent = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        pause_ms = pause_ms ? std::min(2 * pause_ms, 320) : 20;
+        if (spent + pause_ms > m->opt_wait_ms)
+            return fail(MDK_ERR_DEVICE, "LSTM(384) cluster exchange timed out %d times in %ld ms (the later tries without the "
+                                        "overlapped projection): the rl_lstm384 path needs %d CUs of the GPU to itself",
+                        tries, spent, 8 * kWC * 2);
+        std::this_thread::sleep_for(std::chrono::milliseconds(pause_ms));
+    }
 }
 
 // asynchronous mode ("wide_async" = 1): surfaces a time-out of an earlier mdk_rl_forward_dev

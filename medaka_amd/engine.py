@@ -143,18 +143,15 @@ class GruEngine:
         n = t.n_layers
         return {"h2d_ms": t.h2d_ms, "gi_ms": list(t.gi_ms)[:n], "rec_ms": list(t.rec_ms)[:n],
                 "head_ms": t.head_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms,
-                "rec_launches": t.rec_launches, "fused_layers": t.fused_layers}
+                "rec_launches": t.rec_launches, "fused_layers": t.fused_layers, "host_streamed": t.host_streamed}
 
-    def split(self, wait_spot=False):
-        """What the last forward did about splitting the scan (include/medaka_amd.h `mdk_gru_split`); `wait_spot`
-        first waits for the standing spot audit in flight, so that the spot_* counters include it."""
-        if wait_spot:
-            _lib.check(_lib.load().mdk_gru_spot_wait(self._h), "mdk_gru_spot_wait")
+    def split(self):
+        """What the last forward did about splitting the scan (include/medaka_amd.h `mdk_gru_split`)."""
         t = _lib.GruSplit()
         _lib.check(_lib.load().mdk_gru_get_split(self._h, ctypes.byref(t)), "mdk_gru_get_split")
         return {"chunks": t.chunks, "margin": t.margin, "columns": t.columns, "status": _lib.SPLIT_STATUS.get(t.status, t.status),
                 "max_delta": t.max_delta, "fallbacks": t.fallbacks, "audited": bool(t.audited), "audit_max_dp": t.audit_max_dp,
-                "spot_audits": t.spot_audits, "spot_failures": t.spot_failures, "spot_max_dp": t.spot_max_dp}
+                "audits": t.audits, "audit_failures": t.audit_failures, "audit_worst_dp": t.audit_worst_dp}
 
     # -- compute
     def forward_host(self, x, out=None):

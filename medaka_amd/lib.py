@@ -36,14 +36,15 @@ class GruTiming(ctypes.Structure):
     _fields_ = [("h2d_ms", ctypes.c_float), ("gi_ms", ctypes.c_float * 4),
                 ("rec_ms", ctypes.c_float * 4), ("head_ms", ctypes.c_float),
                 ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("rec_launches", ctypes.c_int), ("n_layers", ctypes.c_int), ("fused_layers", ctypes.c_int)]
+                ("rec_launches", ctypes.c_int), ("n_layers", ctypes.c_int), ("host_streamed", ctypes.c_int),
+                ("fused_layers", ctypes.c_int)]
 
 
 class GruSplit(ctypes.Structure):
     _fields_ = [("chunks", ctypes.c_int), ("margin", ctypes.c_int), ("columns", ctypes.c_int),
                 ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int),
-                ("audited", ctypes.c_int), ("audit_max_dp", ctypes.c_float), ("spot_audits", ctypes.c_int),
-                ("spot_failures", ctypes.c_int), ("spot_max_dp", ctypes.c_float)]
+                ("audited", ctypes.c_int), ("audit_max_dp", ctypes.c_float), ("audits", ctypes.c_int),
+                ("audit_failures", ctypes.c_int), ("audit_worst_dp", ctypes.c_float)]
 
 
 class SplitShape(ctypes.Structure):
@@ -68,7 +69,6 @@ ABI = {
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
-    "mdk_gru_spot_wait": (_i, [_vp]),
     "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),

@@ -32,7 +32,9 @@ ZOO = {"maj1":      ("majority",    1,         2500,  300),
        "depthmix":  ("depthmix",    3,         2500,  400),
        "hp":        ("homopolymer", 4,         3000,  300),
        "latch":     ("latch",       5,         2000,  1000),
-       "latch2":    ("latch",       6,         2500,  800)}
+       "latch2":    ("latch",       6,         2600,  1000)}
+# curriculum (latch2): (steps, columns per window, marker distances) -- a latch is learned on short segments first
+STAGES = {"latch2": [(700, 400, (8, 40)), (800, 600, (20, 150)), (1100, 1000, (50, 400))]}
 
 
 def zoo_input(name, n_windows=2, n_cols=3000):
@@ -51,23 +53,28 @@ def train(name, log=print):
     opt = torch.optim.RMSprop(model.parameters(), lr=1e-3)
     loss_fn = torch.nn.CrossEntropyLoss()
     rng = np.random.default_rng(seed)
-    pool_x, pool_y = zoo_tasks.make_pool(task, 768, T, seed=seed)
+    stages = STAGES.get(name, [(steps, T, (50, 600))])
+    assert sum(st[0] for st in stages) == steps
     t0 = time.time()
     acc = 0.0
-    for step in range(steps):
-        if step == steps * 3 // 4:
-            for g in opt.param_groups:
-                g["lr"] = 2.5e-4
-        idx = rng.integers(0, len(pool_x), 32)
-        batch = te.Batch(counts_matrix=torch.from_numpy(pool_x[idx]), labels=torch.from_numpy(pool_y[idx]))
-        opt.zero_grad()
-        loss, metrics = model.process_batch(batch, loss_fn)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()
-        acc = 0.98 * acc + 0.02 * metrics["n_model_correct"] / metrics["n_positions"]
-        if step % 250 == 0 or step == steps - 1:
-            log(f"[{name}] step {step} loss {loss.item():.4f} acc~{acc:.4f} ({time.time() - t0:.0f}s)")
+    step = 0
+    for si, (n_steps, T_s, seg) in enumerate(stages):
+        pool_x, pool_y = zoo_tasks.make_pool(task, 768, T_s, seed=seed + 100 * si, seg=seg)
+        for _ in range(n_steps):
+            if step == steps * 3 // 4:
+                for g in opt.param_groups:
+                    g["lr"] = 2.5e-4
+            idx = rng.integers(0, len(pool_x), 32)
+            batch = te.Batch(counts_matrix=torch.from_numpy(pool_x[idx]), labels=torch.from_numpy(pool_y[idx]))
+            opt.zero_grad()
+            loss, metrics = model.process_batch(batch, loss_fn)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            acc = 0.98 * acc + 0.02 * metrics["n_model_correct"] / metrics["n_positions"]
+            if step % 250 == 0 or step == steps - 1:
+                log(f"[{name}] step {step} (T={T_s}, seg={seg}) loss {loss.item():.4f} acc~{acc:.4f} ({time.time() - t0:.0f}s)")
+            step += 1
     model.normalise = True
     model.eval()
     # held-out accuracy on fresh windows of the task

@@ -105,8 +105,9 @@ def depthmix_window(rng, n_cols):
     return x[0], y[0]
 
 
-def make_pool(task, n_windows, n_cols, seed):
-    """(n_windows, n_cols, 10) float32 features, (n_windows, n_cols) int64 labels ('*ACGT' -> 0..4)."""
+def make_pool(task, n_windows, n_cols, seed, seg=(50, 600)):
+    """(n_windows, n_cols, 10) float32 features, (n_windows, n_cols) int64 labels ('*ACGT' -> 0..4).
+    `seg`: latch task only, shortest / longest distance between two markers."""
     rng = np.random.default_rng([seed, TASKS.index(task)])
     if task == "majority":
         return synth.counts_windows(n_windows, n_cols, depth=50, seed=int(rng.integers(0, 2 ** 31)), return_labels=True)
@@ -115,7 +116,7 @@ def make_pool(task, n_windows, n_cols, seed):
         if task == "homopolymer":
             x, y = homopolymer_window(rng, n_cols, int(rng.choice([25, 50, 90])))
         elif task == "latch":
-            x, y = latch_window(rng, n_cols, 50)
+            x, y = latch_window(rng, n_cols, 50, seg)
         else:
             x, y = depthmix_window(rng, n_cols)
         xs.append(x)

@@ -857,8 +857,43 @@ def test_wide_read_level_fails_fast_without_its_cus():
     if err is None:                    # the tenant was scheduled elsewhere or had finished: then the bits must be right
         assert np.array_equal(out, ref)
     else:
-        assert "timed out" in err and dt < 2.5       # two bounded tries, not seconds of spinning per launch
+        assert "timed out" in err and dt < 4.5       # bounded tries inside the 3 s budget of "wide_wait_ms", never a hang
     assert np.array_equal(e.forward_host(x), ref)                         # CUs back: same bits as before
+    e.close()
+
+
+def test_wide_read_level_retry_budget_and_error_branch():
+    """The host side of a cluster time-out, deterministically (option "wide_inject_timeout" raises the device's time-out
+    flag before a try, as a lost forward leaves it: every launch of that try returns at once and the host finds the
+    flag).  Time-outs that end inside the budget are waited out with growing pauses and give the right bits; more of
+    them than "wide_wait_ms" allows end in MDK_ERR_DEVICE -- on the error branch, within the budget -- and the engine
+    works again afterwards."""
+    import time
+    kw = _wide_kw(True)
+    st = rl_oracle.synth_rl_state(seed=33, **kw)
+    x = rl_oracle.synth_reads(9, 300, 4, use_dwells=True, seed=12)
+    e = engine.RlEngine(st, **kw)
+    e.enable_timing(True)
+    ref = e.forward_host(x)
+    r0 = e.timing()["wide_retries"]
+    e.set_option("wide_inject_timeout", 3)           # the first try and two retries lost, the third retry goes through
+    out = e.forward_host(x)
+    assert np.array_equal(out, ref) and e.timing()["wide_retries"] - r0 == 3
+    e.set_option("wide_wait_ms", 250)
+    e.set_option("wide_inject_timeout", 1000)
+    t0 = time.perf_counter()
+    with pytest.raises(lib.EngineError, match="timed out"):
+        e.forward_host(x)
+    dt = time.perf_counter() - t0
+    assert dt < 1.5, dt
+    e.set_option("wide_inject_timeout", 0)
+    assert np.array_equal(e.forward_host(x), ref)
+    e.set_option("wide_wait_ms", 0)                  # no budget: the second time-out is the error (the round-3 behaviour)
+    e.set_option("wide_inject_timeout", 2)
+    with pytest.raises(lib.EngineError, match="timed out 2 times"):
+        e.forward_host(x)
+    e.set_option("wide_inject_timeout", 1)
+    assert np.array_equal(e.forward_host(x), ref)    # one time-out: the plain-schedule retry answers
     e.close()
 
 

@@ -1,0 +1,178 @@
+"""Evidence for the split scan's claim (medaka_amd/csrc/scan_split.hpp) beyond one weight set and i.i.d. input:
+
+  * SEVEN trained weight sets -- `weights_trained.npz` (round 1: 200 steps of a memory-free majority vote) and the six of
+    tests/golden/weights_zoo.npz (oracle/make_golden_zoo.py: the UNMODIFIED reference's `process_batch`, 2000-4000
+    steps, other seeds, tasks that need memory of a run (homopolymer) and a bit latched for hundreds of columns (latch));
+  * STRUCTURED pileups (medaka_amd.synth.structured_windows): zero-coverage runs of 2000-3000 columns, homopolymers,
+    dinucleotide and tandem repeats, 5x <-> 500x depth cliffs, windows that are all insertion columns.
+
+For every (weight set, input kind) the contract is the same:
+    certified  =>  the delivered probabilities agree with the engine's own sequential scan to the audit tolerance (4e-6)
+                   on EVERY column, and with the PyTorch-CPU oracle to the parity tolerance (2e-5 asserted, 1e-4 contract);
+    rejected   =>  the delivered probabilities ARE the sequential scan's, bit for bit.
+The outcome of every case (status, margin the model escalated to, largest junction difference, largest deviation from
+the sequential scan) is printed and written to gpurun_out/split_evidence.json: the table of DESIGN.md section 4.9."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, usable_cores
+from medaka_amd import engine, synth
+from oracle import oracle
+from test_parity_gpu import _check
+
+pytestmark = pytest.mark.gpu
+ZOO_PATH = os.path.join(GOLD, "weights_zoo.npz")
+
+
+@pytest.fixture(autouse=True)
+def product_default(monkeypatch):
+    monkeypatch.delenv("MDK_SCAN_SPLIT", raising=False)
+    monkeypatch.delenv("MDK_SCAN_SPLIT_MARGIN", raising=False)
+
+
+def zoo_names():
+    if not os.path.exists(ZOO_PATH):
+        return []
+    return sorted({k.split("/")[0] for k in np.load(ZOO_PATH).files})
+
+
+def weights(name, gold):
+    if name == "trained":
+        return gold["weights_trained"]
+    z = np.load(ZOO_PATH)
+    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+
+
+def _record(row):
+    path = os.path.join(ROOT, "gpurun_out", "split_evidence.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    rows = json.load(open(path)) if os.path.exists(path) else []
+    rows = [r for r in rows if (r["weights"], r["input"], r.get("shape")) != (row["weights"], row["input"], row.get("shape"))]
+    rows.append(row)
+    json.dump(rows, open(path, "w"), indent=1)
+
+
+def _case(e, x, wname, kind, st, n_oracle=3):
+    out = e.forward_host(x)
+    info = e.split()
+    e.set_option("scan_split", 0)
+    seq = e.forward_host(x)
+    e.set_option("scan_split", 1)
+    d = float(np.abs(out - seq).max())
+    row = {"weights": wname, "input": kind, "shape": list(x.shape[:2]), "status": info["status"], "chunks": info["chunks"],
+           "margin": info["margin"], "max_junction_delta": info["max_delta"], "rejected_certificates": info["fallbacks"],
+           "max_dp_vs_sequential": d, "argmax_identical": bool(np.array_equal(out.argmax(-1), seq.argmax(-1)))}
+    print(json.dumps(row))
+    _record(row)
+    if info["status"] == "certified":
+        assert info["chunks"] >= 2
+        assert d <= 4e-6, row
+        assert row["argmax_identical"] or wname in ("init",), row
+    else:
+        assert info["status"] in ("rejected", "disabled", "not used"), row
+        assert np.array_equal(out, seq), row                        # the sequential scan's bits
+    torch.set_num_threads(usable_cores())
+    ref = oracle.make_torch_oracle(st).predict(x[:n_oracle]).numpy()
+    _check(out[:n_oracle], ref, what=f"{wname} / {kind} vs the PyTorch-CPU oracle ({info['status']})", strict_argmax=False)
+    return row
+
+
+@pytest.mark.parametrize("kind", synth.STRUCTURED_KINDS)
+def test_structured_pileups_on_the_round1_weights(gold, kind):
+    """16 windows x 10000 columns = 16 chunks per window at the product default."""
+    x = synth.structured_windows(kind, 16, 10000, depth=50, seed=77)
+    e = engine.GruEngine(gold["weights_trained"])
+    row = _case(e, x, "trained", kind, gold["weights_trained"])
+    e.close()
+    assert row["status"] in ("certified", "rejected", "disabled")
+
+
+@pytest.mark.parametrize("wname", zoo_names() or [pytest.param("none", marks=pytest.mark.skip(reason="no weights_zoo.npz"))])
+def test_weight_zoo_on_iid_and_structured_pileups(gold, wname):
+    """Every zoo set: its reference golden (oracle/make_golden_zoo.py `zoo_input`, the unmodified reference's output), then
+    i.i.d. pileups and every structured kind, 16 x 10000 each, a fresh engine per input so that every case starts from
+    the default margin."""
+    from oracle.make_golden_zoo import zoo_input
+    st = weights(wname, gold)
+    zo = np.load(os.path.join(GOLD, "zoo_outputs.npz"))
+    e = engine.GruEngine(st)
+    out = e.forward_host(zoo_input(wname))
+    _check(out, zo[wname], what=f"zoo {wname} vs the unmodified reference ({e.split()['status']})", strict_argmax=True)
+    e.close()
+    rows = []
+    for kind in ("iid",) + synth.STRUCTURED_KINDS:
+        x = (synth.counts_windows(16, 10000, depth=50, seed=5) if kind == "iid"
+             else synth.structured_windows(kind, 16, 10000, depth=50, seed=78))
+        e = engine.GruEngine(st)
+        rows.append(_case(e, x, wname, kind, st, n_oracle=2))
+        e.close()
+    # and on windows of the set's own task, where its memory is actually used
+    from oracle import zoo_tasks
+    from oracle.make_golden_zoo import ZOO
+    x = zoo_tasks.make_pool(ZOO[wname][0], 16, 10000, seed=4242)[0]
+    e = engine.GruEngine(st)
+    rows.append(_case(e, x, wname, "own task", st, n_oracle=2))
+    e.close()
+    print(f"{wname}: " + ", ".join(f"{r['input']}={r['status']}@{r['margin']}" for r in rows))
+
+
+def test_full_batch_margins_of_every_weight_set(gold):
+    """The margin each weight set needs at BASELINE configs[1] (200 x 10000, i.i.d. 50x pileups): forced margins 32 ... 512,
+    certificate + deviation from the sequential scan.  This is the data behind the default."""
+    x = np.concatenate([synth.counts_windows(8, 10000, depth=50, seed=100 + s) for s in range(25)])
+    table = {}
+    for wname in ["trained"] + zoo_names():
+        st = weights(wname, gold)
+        e = engine.GruEngine(st)
+        e.set_option("scan_split_audit", 0)
+        e.set_option("scan_split", 0)
+        seq = e.forward_host(x)
+        table[wname] = {}
+        for g in (32, 64, 96, 128, 192, 256, 512):
+            e.set_option("scan_split_margin", g)
+            e.set_option("scan_split", 5 if g <= 256 else 4)          # forced chunk count: a rejection is not escalated
+            out = e.forward_host(x)
+            info = e.split()
+            d = float(np.abs(out - seq).max())
+            table[wname][g] = {"status": info["status"], "max_junction_delta": info["max_delta"], "max_dp_vs_sequential": d}
+            if info["status"] == "certified":
+                assert d <= 4e-6, (wname, g, info, d)
+            else:
+                assert np.array_equal(out, seq), (wname, g)
+        e.close()
+        need = min((g for g, r in table[wname].items() if r["status"] == "certified"), default=None)
+        print(f"{wname}: smallest certified margin {need}; " +
+              ", ".join(f"{g}:{r['status'][:4]}({r['max_junction_delta']:.1e})" for g, r in table[wname].items()))
+    path = os.path.join(ROOT, "gpurun_out", "split_margins.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(table, open(path, "w"), indent=1)
+
+
+def test_standing_audit(gold):
+    """With "scan_split_audit" = 1 the first certified call is audited and then every "scan_split_audit_every"-th one:
+    run again as the sequential scan on the device, compared in full.  Counters in `mdk_gru_split`."""
+    x = synth.counts_windows(24, 10000, depth=50, seed=9)
+    e = engine.GruEngine(gold["weights_trained"])
+    e.set_option("scan_split_audit_every", 3)
+    audited, outs = [], []
+    for _ in range(8):
+        outs.append(e.forward_host(x))
+        info = e.split()
+        assert info["status"] == "certified", info
+        audited.append(info["audited"])
+    assert audited == [True, False, False, True, False, False, True, False], audited
+    assert info["audits"] == 3 and info["audit_failures"] == 0 and 0.0 < info["audit_worst_dp"] <= 4e-6, info
+    assert all(np.array_equal(o, outs[0]) for o in outs)
+    e.set_option("scan_split_audit_every", 0)            # only first calls
+    for _ in range(5):
+        e.forward_host(x)
+    assert e.split()["audits"] == 3
+    e.set_option("scan_split_audit", 0)
+    e.set_option("scan_split_audit_every", 1)
+    e.forward_host(x)
+    assert e.split()["audits"] == 3 and not e.split()["audited"]
+    e.close()

@@ -284,6 +284,47 @@ def test_counts_in_decoded_out_at_full_size_through_the_split_scan(gold):
     e.close()
 
 
+@pytest.mark.parametrize("B,T", [(200, 10000), (100, 10000), (10, 10000), (37, 9999), (3, 3073), (1, 10000)])
+def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
+    """`mdk_gru_forward` of a split call with PAGE-LOCKED buffers (what `predict_on_batch` hands over): x comes in and the
+    probabilities leave in column slabs under the recurrences, through copy kernels on the buffers' device-visible
+    addresses (api.hip run_split / forward_pass HostIO).  Only data movement and the cut of the scans into resumed
+    launches differ: the bits must be those of the device entry and of the one-copy-each-way path (pageable buffers,
+    or option "stream_host" = 0) -- pinned in / pageable out and the reverse included."""
+    x = synth.counts_windows(B, T, depth=40, seed=11 * B + T)
+    e = engine.GruEngine(gold["weights_trained"])
+    e.enable_timing(True)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty(B, T, 5, device="cuda")
+    e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    info = e.split()
+    assert info["status"] == "certified", info
+    want = yd.cpu().numpy()
+    plain = e.forward_host(x)                                  # pageable in, pageable out
+    assert e.timing()["host_streamed"] == 0 and np.array_equal(plain, want)
+    pin_x, pin_p = engine.PinnedArray(x.shape), engine.PinnedArray(want.shape)
+    pin_x.array[...] = x
+    streamable = e.split()["columns"] >= 512
+    for rep in range(3):                                       # repeated: the slabs land in recycled buffers
+        pin_p.array[...] = -1.0
+        out = e.forward_host(pin_x.array, out=pin_p.array)
+        assert e.timing()["host_streamed"] == (3 if streamable else 0), (e.timing(), e.split())
+        assert np.array_equal(out, want), (rep, float(np.abs(out - want).max()))
+    assert np.array_equal(e.forward_host(pin_x.array), want) and e.timing()["host_streamed"] == (1 if streamable else 0)
+    pin_p.array[...] = -1.0
+    assert np.array_equal(e.forward_host(x, out=pin_p.array), want) and e.timing()["host_streamed"] == (2 if streamable else 0)
+    e.set_option("stream_host", 0)
+    assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), want) and e.timing()["host_streamed"] == 0
+    e.set_option("stream_host", 1)
+    # a view into a larger page-locked block at an odd float offset (4-byte aligned only): scalar copies, same bits
+    big = engine.PinnedArray((x.size + 3,))
+    big.array[1:1 + x.size] = x.ravel()
+    odd = big.array[1:1 + x.size].reshape(x.shape)
+    assert np.array_equal(e.forward_host(odd, out=pin_p.array), want)
+    e.close()
+
+
 def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
     """Regression (found by the split scan's certificate): in half-precision mode 16-window work-groups of a batch
     with an odd number of 8-window tiles ran their surplus lanes on a copy of the last window -- with the fused
