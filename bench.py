@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--scan-split", type=int, default=None,
                     help="split scan (include/medaka_amd.h \"scan_split\"): default = the engine's (1, auto); 0 = the sequential scan "
                          "only; n >= 2 = force n chunks per window")
-    ap.add_argument("--scan-split-margin", type=int, default=None, help="warm-up columns on either side of a chunk (default 256)")
+    ap.add_argument("--scan-split-margin", type=int, default=None, help="warm-up columns on either side of a chunk (default: the engine's, 128)")
     ap.add_argument("--model", default="gru", choices=["gru", "rl128", "rl384"],
                     help="gru: the headline consensus model; rl128 / rl384: read-level models (BASELINE config 4b)")
     ap.add_argument("--rl-depth", type=int, default=50, help="read-level models: reads per window")

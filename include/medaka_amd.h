@@ -66,8 +66,9 @@ typedef struct {
     float total_ms;       /* first kernel start -> last kernel end (device-resident region) */
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
-    int host_streamed;    /* split calls through mdk_gru_forward: bit 0 = x came in, bit 1 = the probabilities left in column
-                             slabs under the recurrences (page-locked buffers); 0 = one copy before / after the forward */
+    int host_streamed;    /* split calls through mdk_gru_forward: bit 1 = the probabilities left in column chunks under the
+                             tail of the last recurrence ("stream_host" = 2; else one copy after the forward); bit 2 = x had
+                             been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call) */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
                              "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both) */
 } mdk_gru_timing;
@@ -117,6 +118,16 @@ int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weights, int n_
  * each side); pageable and page-locked buffers are both accepted.
  */
 int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host);
+
+/* Early hand-over of the NEXT batch (no reference counterpart; what the engine's `Batch.collate` does from the reference's
+ * Batcher thread, prediction.py:356-370): starts the host -> device copy of x_host (B x T x num_features fp32, page-locked
+ * for a truly asynchronous copy) on a stream of its own and returns at once with a token.  mdk_gru_forward_staged(token,
+ * ...) later answers exactly like mdk_gru_forward(x_host, ...) without waiting for PCIe: the 1.4 ms an 80 MB batch
+ * takes to cross overlap the previous batch's forward.  x_host must stay untouched until the staged forward returns.
+ * Twelve batches can be staged ahead (the reference's loader keeps up to 8 in its queue); a token that was pushed out (or never redeemed) makes mdk_gru_forward_staged
+ * return MDK_ERR_ARG -- call mdk_gru_forward instead.  Callable from another thread than the forwards. */
+int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T, unsigned long long *token);
+int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host);
 
 /*
  * Same contraction with device-resident buffers (what `GRUModel.forward`, gru.py:58-72, is to
@@ -175,8 +186,10 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
- *   "stream_host"          = 1 | 0                  mdk_gru_forward: copy x in / probabilities out in time slabs
- *                                                   under the recurrences (0: one copy before, one after)
+ *   "stream_host"          = 1 | 0 | 2              mdk_gru_forward, sequential scan: copy x in / probabilities out in time
+ *                                                   slabs under the recurrences (0: one copy before, one after).  A split
+ *                                                   call copies once each way (its recurrences hold every CU: nothing can
+ *                                                   run beside them); 2 also streams a split call's result (experiments)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
  *                                                   larger batches run as equal passes
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid

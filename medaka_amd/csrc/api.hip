@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -82,6 +83,7 @@ struct mdk_gru {
     hipStream_t side = nullptr;              // projection GEMM of layer 1 under the tail of layer 0
     hipStream_t copy_in = nullptr;           // host path: time slabs of x, host -> device, ahead of the layer-0 recurrence
     hipStream_t copy_out = nullptr;          // host path: finished probability columns, device -> host
+    hipStream_t copy_out2 = nullptr;         // split host path: every other chunk copy (two DMA engines side by side)
     std::vector<hipEvent_t> ov_ev;           // event pool of one forward pass (no timing)
     size_t ov_next = 0;
     float *gi2 = nullptr;                    // its own gi buffer (layer 0's fallback may still read gi)
@@ -104,6 +106,14 @@ struct mdk_gru {
     int split_audited_key = 0;               // margin | precision << 16 whose first certified call has been audited (0 = none yet)
     float *audit = nullptr;                  // the sequential scan's probabilities of an audited call
     size_t audit_cap = 0;
+    // early hand-over of the next batch (mdk_gru_stage_input): its host -> device copy runs on `stage_stream` while the
+    // caller's thread is still inside the forward of the previous one
+    struct StageSlot { unsigned long long token = 0; bool busy = false; float *dev = nullptr; size_t cap = 0; int B = 0, T = 0; hipEvent_t ready = nullptr; };
+    StageSlot stage[12];     // the reference's loader runs up to 8 batches ahead of the model (prediction.py:229, batch_cache_size)
+    unsigned long long stage_next_token = 1;
+    hipStream_t stage_stream = nullptr;
+    std::mutex stage_mu;
+    long staged_used = 0;
     // standing audit: every `opt_split_audit_every`-th certified call is ALSO run as the sequential scan (run_forward)
     int opt_split_audit_every = 256;
     long split_calls_since_audit = 0;
@@ -127,6 +137,8 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
+    if (m->stage_stream) { (void)hipStreamSynchronize(m->stage_stream); (void)hipStreamDestroy(m->stage_stream); }
+    for (auto &sl : m->stage) { free_dev(sl.dev); if (sl.ready) (void)hipEventDestroy(sl.ready); }
     if (m->split_host) (void)hipHostFree(m->split_host);
     for (auto e : m->ev) (void)hipEventDestroy(e);
     for (auto e : m->ov_ev) (void)hipEventDestroy(e);
@@ -134,6 +146,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->copy_in) (void)hipStreamDestroy(m->copy_in);
     if (m->copy_out) (void)hipStreamDestroy(m->copy_out);
+    if (m->copy_out2) (void)hipStreamDestroy(m->copy_out2);
     delete m;
 }
 
@@ -171,7 +184,8 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_out2, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
 
     for (int l = 0; l < L; ++l) {
@@ -349,7 +363,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "deferred_store")) {
         m->opt_deferred_store = value ? 1 : 0;
     } else if (!strcmp(key, "stream_host")) {
-        m->opt_stream_host = value ? 1 : 0;
+        m->opt_stream_host = value < 0 ? 0 : (value > 2 ? 2 : value);     // 2: also the result of a split call (experiments)
     } else if (!strcmp(key, "gpu_share")) {
         if (value < 1 || value > 8) return fail(MDK_ERR_ARG, "gpu_share must be 1..8");
         m->opt_gpu_share = value;
@@ -462,77 +476,11 @@ enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
 struct HostIO {
     const float *x_host = nullptr;   // (nb, T, F) of this pass, or null: x is already on the device
     float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
-    // Split calls whose host buffers are page-locked (run_split): the device-visible addresses of the caller's buffers.
-    // x lands in `x_real` -- the real (B, T, F) layout, every column crossing PCIe once -- slab by slab in the order the
-    // chunks' scans need it and is gathered from there into the virtual batch; the probabilities leave from the real
-    // (B, T, C) device result chunk by chunk behind the head.  Both by k_copy_cols, on the copy streams.
-    const float *x_map = nullptr;
-    float *x_real = nullptr;
-    float *p_map = nullptr;
 };
 
 // the streamed host path of a split call cuts the virtual windows' scans into phases (forward_pass): layer 0 fused, and
 // a virtual window long enough for that to be worth the launches
 constexpr int kSplitStreamMinT = 512;
-
-// Device-visible address of a page-locked host buffer (hipHostMalloc / hipHostRegister: torch's pinned allocator,
-// mdk_host_alloc), or null for ordinary pageable memory.
-static void *mapped_ptr(const void *host) {
-    hipPointerAttribute_t at;
-    memset(&at, 0, sizeof(at));
-    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
-    return at.devicePointer;
-}
-
-// [a, b) minus what `cover` holds is appended to `fresh`; `cover` (sorted, disjoint) then includes [a, b)
-struct ColRange { int a, b; };
-static void claim_range(std::vector<ColRange> &cover, int a, int b, std::vector<ColRange> &fresh) {
-    if (a >= b) return;
-    int cur = a;
-    std::vector<ColRange> merged;
-    bool placed = false;
-    ColRange add{a, b};
-    for (const ColRange &c : cover) {
-        if (c.b <= a || c.a >= b) {                 // disjoint (touching counts as disjoint for the subtraction)
-            if (c.b == a) { add.a = c.a; continue; }
-            if (c.a == b) { add.b = c.b; continue; }
-            if (!placed && c.a > b) { merged.push_back(add); placed = true; }
-            merged.push_back(c);
-            continue;
-        }
-        if (c.a > cur) fresh.push_back({cur, c.a});
-        cur = std::max(cur, c.b);
-        add.a = std::min(add.a, c.a);
-        add.b = std::max(add.b, c.b);
-    }
-    if (cur < b) fresh.push_back({cur, b});
-    if (!placed) merged.push_back(add);
-    std::sort(merged.begin(), merged.end(), [](const ColRange &x, const ColRange &y) { return x.a < y.a; });
-    // `add` may have been placed before growing: rebuild it at its final extent
-    std::vector<ColRange> out;
-    for (const ColRange &c : merged) {
-        if (!out.empty() && c.a <= out.back().b) out.back().b = std::max(out.back().b, c.b);
-        else out.push_back(c);
-    }
-    cover.swap(out);
-}
-
-// ranges of a (B, T, E) array, kMaxCopyRanges per launch
-static void launch_copy_cols(const float *src, float *dst, int B, int T, int E, const std::vector<ColRange> &ranges, hipStream_t st) {
-    const bool vec2 = E % 2 == 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0;
-    for (size_t r0 = 0; r0 < ranges.size(); r0 += kMaxCopyRanges) {
-        CopyPlan pl;
-        pl.n = (int)std::min<size_t>(kMaxCopyRanges, ranges.size() - r0);
-        pl.cum[0] = 0;
-        for (int i = 0; i < pl.n; ++i) { pl.a[i] = ranges[r0 + i].a; pl.cum[i + 1] = pl.cum[i] + (ranges[r0 + i].b - ranges[r0 + i].a); }
-        const long units = (long)pl.cum[pl.n] * E / (vec2 ? 2 : 1) * B;
-        if (units <= 0) continue;
-        const unsigned blocks = (unsigned)std::min<long>((units + 1023) / 1024, 256);
-        if (vec2) hipLaunchKernelGGL(k_copy_cols<2>, dim3(blocks), dim3(256), 0, st, src, dst, B, T, E, pl);
-        else hipLaunchKernelGGL(k_copy_cols<1>, dim3(blocks), dim3(256), 0, st, src, dst, B, T, E, pl);
-    }
-}
 
 static int pool_event(mdk_gru *m, hipEvent_t *out) {
     if (m->ov_next == m->ov_ev.size()) {
@@ -555,8 +503,8 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const int n_tiles = (nb + kTileWin - 1) / kTileWin;
     int rc;
     const float *in = x;
-    const bool io_in = io && io->x_host, io_out = io && io->p_host;
-    const bool sp_in = sp && io && io->x_map, sp_out = sp && io && io->p_map;     // split call on page-locked host buffers
+    const bool io_in = io && io->x_host, io_out = io && io->p_host && !sp;
+    const bool sp_out = sp && io && io->p_host;     // split call: `probs` is the real (B, T, C) result, io->p_host the caller's buffer
     const size_t x_bytes = (size_t)M * m->desc.num_features * sizeof(float);
     const size_t p_bytes = (size_t)M * m->desc.num_classes * sizeof(float);
     m->ov_next = 0;
@@ -672,10 +620,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                            (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && !overlap_ok));
     const bool overlap = overlap_ok && !fuse_proj;
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
-    const bool stream_in = ((io_in && can_chunk) || (sp_in && can_chunk_sp)) && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
+    const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
     const bool stream_out = ((io_out && can_chunk) || (sp_out && can_chunk_sp)) && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
-    if ((sp_in && !stream_in) || (sp_out && !stream_out)) return fail(MDK_ERR_ARG, "internal: split host streaming asked for a shape that cannot be chunked");
-    std::vector<ColRange> x_cover;      // real columns of x already landed on the device (split host path)
+    if (sp_out && !stream_out) return fail(MDK_ERR_ARG, "internal: split host streaming asked for a shape that cannot be chunked");
     const int F = m->desc.num_features, C = m->desc.num_classes;
     // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
     auto copy_in_cols = [&](int t0, int nt) -> int {
@@ -684,19 +631,6 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                                  io->x_host + (size_t)t0 * F, (size_t)T * F * sizeof(float),
                                  (size_t)nt * F * sizeof(float), (size_t)nb, hipMemcpyHostToDevice, m->copy_in));
         return MDK_OK;
-    };
-    // split host path: local columns [t0, t0 + nt) of every chunk = real columns start[k] + [t0, t0 + nt): what has not
-    // crossed PCIe yet comes over (every real column once: neighbouring chunks share their margins), then the slab is
-    // gathered from the real layout into the virtual batch; both on the copy stream
-    auto split_in_cols = [&](int t0, int nt) {
-        if (nt <= 0) return;
-        std::vector<ColRange> fresh;
-        for (int k = 0; k < sp->S; ++k) claim_range(x_cover, sp->start[k] + t0, sp->start[k] + t0 + nt, fresh);
-        launch_copy_cols(io->x_map, io->x_real, sp->B, sp->T, F, fresh, m->copy_in);
-        const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(io->x_real) % 8 == 0) ? 2 : 1;
-        const size_t n = (size_t)nb * nt * F / vec;
-        hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 4)), dim3(256), 0, m->copy_in,
-                           (const float *)io->x_real, const_cast<float *>(x), *sp, F, vec, t0, nt);
     };
     if (io_in && !stream_in)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x), io->x_host, x_bytes, hipMemcpyHostToDevice, s));
@@ -732,7 +666,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         const bool fused_proj = l >= 1 && fuse_proj;
         // device-resident x: the packing of all but the first slab pair runs on the side stream under the
         // first recurrence phases instead of in front of them (0.25 ms of k_pack_x at 200 x 10000)
-        const bool dev_slabs = !io_in && !sp_in && fuse && can_chunk && l == 0 && m->opt_overlap;
+        const bool dev_slabs = !io_in && fuse && can_chunk && l == 0 && m->opt_overlap;
         const bool slabs = (stream_in || dev_slabs) && l == 0;       // this layer's recurrence starts slab by slab
         const bool side_gemm = overlap && l == 0;                  // layer 1's projection behind this layer's chunks
         const bool side_head = (overlap || stream_out) && l == L - 1 && L >= 2;   // classifier head behind the chunks
@@ -832,7 +766,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             } else if (side_head) {
                 // halving chunks: what follows the last recurrence launch (its head chunk, and on the host path
                 // the copy of that chunk) is T/32 columns instead of T/12
-                for (int k = 1; k <= 4; ++k) ph.push_back(T / 2 + ((T / 2) - ((T / 2) >> k)) / kGemmSteps * kGemmSteps);
+                // (a split call's chunk is S copies per column range, ~20 us each whatever their size: two halvings -- the last
+                // quarter of the columns stays for the end -- instead of four; profiles/r4_experiments/host_path_timeline_v3.txt)
+                for (int k = 1; k <= (sp ? 2 : 4); ++k) ph.push_back(T / 2 + ((T / 2) - ((T / 2) >> k)) / kGemmSteps * kGemmSteps);
             }
             ph.push_back(T);
             const int n_ph = (int)ph.size() - 1;
@@ -862,11 +798,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 } else if (slabs && p < n_first) {
                     // columns [rs0, rs0+rns) and their mirror [T-rs0-rns, T-rs0); the last pair is adjacent
                     const int lo = rs0, hi = T - rs0 - rns;
-                    if (sp_in) {
-                        if (lo + rns == hi) split_in_cols(lo, 2 * rns);
-                        else { split_in_cols(lo, rns); split_in_cols(hi, rns); }
-                    }
-                    else if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
+                    if (lo + rns == hi) { if ((rc = copy_in_cols(lo, 2 * rns))) return rc; }
                     else { if ((rc = copy_in_cols(lo, rns)) || (rc = copy_in_cols(hi, rns))) return rc; }
                     hipEvent_t ev;
                     if ((rc = pool_event(m, &ev))) return rc;
@@ -936,22 +868,31 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
     if (sp_out) {
-        // split host path: each head chunk delivered, for chunk k, the real columns core_k /\ (start[k] + [t0, t0 + nt)):
-        // they leave for the caller's page-locked buffer behind the chunk's event, on the copy stream
+        // split host path: each head chunk delivered, for chunk k, the real columns core_k /\ (start[k] + [t0, t0 + nt)): they
+        // leave for the caller's buffer behind the chunk's event as 2-D DMA copies (B rows of a few KB: 37-50 GB/s,
+        // profiles/r4_experiments/dma2d_probe.txt) -- DMA, not a copy kernel: any kernel that talks to host memory from
+        // the recurrence's CUs stalls it (profiles/r4_experiments/README.md)
+        int n_copy = 0;
         for (const OutRange &r : out_ranges) {
-            std::vector<ColRange> cols;
+            HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
+            HIP_TRY(hipStreamWaitEvent(m->copy_out2, r.ready, 0));
             for (int k = 0; k < sp->S; ++k) {
                 const int a = std::max(sp->core0[k], sp->start[k] + r.t0), b = std::min(sp->core0[k + 1], sp->start[k] + r.t0 + r.nt);
-                if (a < b) cols.push_back({a, b});
+                if (a >= b) continue;
+                // (copies alternate between two streams: each costs ~10 us of set-up on top of its bytes, and two DMA engines
+                // work side by side)
+                HIP_TRY(hipMemcpy2DAsync(io->p_host + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
+                                         probs + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
+                                         (size_t)(b - a) * C * sizeof(float), (size_t)sp->B, hipMemcpyDeviceToHost,
+                                         (n_copy++ & 1) ? m->copy_out2 : m->copy_out));
             }
-            HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
-            launch_copy_cols(probs, io->p_map, sp->B, sp->T, C, cols, m->copy_out);
         }
-        hipEvent_t done;
-        if ((rc = pool_event(m, &done))) return rc;
-        HIP_TRY(hipEventRecord(done, m->copy_out));
-        HIP_TRY(hipStreamWaitEvent(s, done, 0));
-        HIP_TRY(hipGetLastError());
+        for (hipStream_t cs : {m->copy_out, m->copy_out2}) {
+            hipEvent_t done;
+            if ((rc = pool_event(m, &done))) return rc;
+            HIP_TRY(hipEventRecord(done, cs));
+            HIP_TRY(hipStreamWaitEvent(s, done, 0));
+        }
     } else if (io_out) {
         if (out_ranges.empty()) {      // head not chunked, or its chunks were not streamed: one copy behind it
             HIP_TRY(hipMemcpyAsync(io->p_host, probs, p_bytes, hipMemcpyDeviceToHost, s));
@@ -1097,17 +1038,20 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     // The host buffers cross PCIe whole, as one copy each way, around the device-resident split forward: the time-slab
     // streaming of the sequential host path would have to copy S strided pieces per slab, and strided copies with
     // short rows run at half the rate of a contiguous one (profiles/r3_experiments/scan_split/host_path.txt)
-    // Host buffers.  Page-locked ones (what `predict_on_batch` hands over: medaka_amd.torch_ext's collate buffer in, a pinned
-    // result tensor out; mdk_host_alloc for C callers) are read and written by copy KERNELS through their device-visible
-    // addresses, a slab of columns at a time under the recurrences (forward_pass, HostIO).  Pageable buffers cross PCIe
-    // whole, one copy each way around the device-resident forward: the time-slab DMA copies of the sequential host path
-    // would be S strided pieces per slab at half the PCIe rate (profiles/r3_experiments/scan_split/host_path.txt).
-    const bool can_stream = split_stream_ok(m, sp.Tv);
-    const float *x_map = (can_stream && x_host) ? static_cast<const float *>(mapped_ptr(x_host)) : nullptr;
-    float *p_map = (can_stream && probs_host) ? static_cast<float *>(mapped_ptr(probs_host)) : nullptr;
-    if (x_host && !x_map)
+    // Host buffers.  x crosses PCIe whole, one contiguous copy in front of the forward: all of it is needed within the
+    // first half of layer 0 (1 ms of work against 1.4 ms of PCIe), so slabs gain nothing -- measured both as DMA slabs and
+    // as copy kernels on the mapped buffer (profiles/r4_experiments/README.md); callers that can, hand x over early
+    // (medaka_amd.torch_ext: the batch is on its way to the device while the previous one is still being computed).
+    // The probabilities leave chunk by chunk behind the classifier head, as 2-D DMA copies under the tail of the last
+    // recurrence (forward_pass); what stays exposed is the last chunk.
+    // ... and gains nothing while a separate classifier-head kernel has to run beside a recurrence that holds every CU: the
+    // head chunks crawl until the recurrence is over and everything serialises at the end (9.4 ms against 9.1,
+    // profiles/r4_experiments/host_path_timeline_v4_dma_out.txt).  "stream_host" = 2 forces it (experiments); by default a
+    // split call copies its result out once, behind the head.
+    const bool stream_out = probs_host && m->opt_stream_host == 2 && split_stream_ok(m, sp.Tv);
+    if (x_host)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
-    if (!x_map) {
+    {
         // float2 copies need 8-byte aligned rows: an even feature count and a caller's pointer that is not on an odd float
         const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 8 == 0) ? 2 : 1;
         const size_t n = cols * F / vec;
@@ -1115,16 +1059,16 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
                            x_dev, m->xv, sp, (int)F, vec, 0, sp.Tv);
     }
     HostIO io;
-    io.x_map = x_map; io.x_real = const_cast<float *>(x_dev); io.p_map = p_map;
-    m->last.host_streamed = (x_map ? 1 : 0) | (p_map ? 2 : 0);
+    io.p_host = stream_out ? probs_host : nullptr;
+    m->last.host_streamed = stream_out ? 2 : 0;
     EvTimer tm{m, s};
-    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, (x_map || p_map) ? &io : nullptr, &sp);
+    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, stream_out ? &io : nullptr, &sp);
     if (rc) return rc;
     hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
                        (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);
     HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipGetLastError());
-    if (probs_host && !p_map)
+    if (probs_host && !stream_out)
         HIP_TRY(hipMemcpyAsync(probs_host, probs_dev, (size_t)sp.B * sp.T * C * sizeof(float), hipMemcpyDeviceToHost, s));
     if ((rc = finish_timing(m, tm, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
@@ -1279,6 +1223,62 @@ static int ensure_staging(mdk_gru *m, size_t nx, size_t np) {
         m->p_cap = np;
     }
     return MDK_OK;
+}
+
+// ---- early hand-over of a batch (the engine's Batch.collate calls this from the reference's Batcher thread) --------
+extern "C" int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T, unsigned long long *token) {
+    if (!m || !token) return fail(MDK_ERR_ARG, "null argument");
+    *token = 0;
+    if (B <= 0 || T <= 0 || !x_host) return fail(MDK_ERR_ARG, "bad batch B=%d T=%d", B, T);
+    HIP_TRY(hipSetDevice(m->device));
+    std::lock_guard<std::mutex> lock(m->stage_mu);
+    if (!m->stage_stream) HIP_TRY(hipStreamCreateWithFlags(&m->stage_stream, hipStreamNonBlocking));
+    // a free slot, else the one staged longest ago (a token nobody redeemed in time simply stops being valid); never the
+    // slot a forward is reading
+    mdk_gru::StageSlot *sl = nullptr;
+    for (auto &c : m->stage)
+        if (!c.busy && (!sl || c.token < sl->token)) sl = &c;
+    if (!sl) return fail(MDK_ERR_ARG, "no staging slot free");
+    const size_t n = (size_t)B * T * m->desc.num_features;
+    if (sl->ready) HIP_TRY(hipEventSynchronize(sl->ready));        // (an unredeemed copy into this slot may still be running)
+    if (n > sl->cap) {
+        free_dev(sl->dev); sl->dev = nullptr; sl->cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl->dev, n * sizeof(float)));
+        sl->cap = n;
+    }
+    if (!sl->ready) HIP_TRY(hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(sl->dev, x_host, n * sizeof(float), hipMemcpyHostToDevice, m->stage_stream));
+    HIP_TRY(hipEventRecord(sl->ready, m->stage_stream));
+    sl->B = B; sl->T = T;
+    sl->token = m->stage_next_token++;
+    *token = sl->token;
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    if (!probs_host || token == 0) return fail(MDK_ERR_ARG, "null buffer / token");
+    HIP_TRY(hipSetDevice(m->device));
+    mdk_gru::StageSlot *sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(m->stage_mu);
+        for (auto &c : m->stage)
+            if (c.token == token && c.B == B && c.T == T && !c.busy) { sl = &c; c.busy = true; c.token = 0; }
+    }
+    if (!sl) return fail(MDK_ERR_ARG, "unknown or expired staging token (use mdk_gru_forward)");
+    const size_t np = (size_t)B * T * m->desc.num_classes;
+    int rc = ensure_staging(m, 0, np);
+    if (!rc && hipStreamWaitEvent(m->stream, sl->ready, 0) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!rc) rc = run_forward(m, sl->dev, B, T, m->p_dev, m->stream, nullptr, probs_host);
+    if (rc) (void)hipDeviceSynchronize();
+    else if (hipStreamSynchronize(m->stream) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamSynchronize failed");
+    {
+        std::lock_guard<std::mutex> lock(m->stage_mu);
+        sl->busy = false;
+    }
+    m->staged_used++;
+    m->last.host_streamed |= 4;
+    return rc;
 }
 
 extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host) {

@@ -43,7 +43,7 @@ constexpr float kAuditTolHalf = 4.0e-4f;
 
 // x (B, T, F) -> xv (S*B, Tv, F), local columns [t_lo, t_lo + nt) of every virtual window: rows of nt*F floats, copied as
 // float2 (every row starts on a multiple of 2*F floats only when F is even: the odd case falls back to scalar copies
-// through `vec` = 1).  The whole batch is t_lo = 0, nt = Tv; the streamed host path gathers slab by slab.
+// through `vec` = 1).  The whole batch is t_lo = 0, nt = Tv.
 static __global__ __launch_bounds__(256) void k_split_gather(const float *__restrict__ x, float *__restrict__ xv,
                                                              SplitPlan p, int F, int vec, int t_lo, int nt) {
     const long row_elems = (long)nt * F / vec;
@@ -57,47 +57,6 @@ static __global__ __launch_bounds__(256) void k_split_gather(const float *__rest
             reinterpret_cast<float2 *>(xv + dst)[e] = reinterpret_cast<const float2 *>(x + src)[e];
         else
             xv[dst + e] = x[src + e];
-    }
-}
-
-// Column ranges of a (B, T, E) array copied between two address spaces one of which may be PAGE-LOCKED HOST MEMORY
-// mapped into the device: the streamed host path of a split call moves x in and the probabilities out with this kernel,
-// a slab of columns at a time, under the recurrences (api.hip run_split).  A DMA copy of the same slab is S strided
-// 2-D copies of short rows, which run at half the PCIe rate (profiles/r3_experiments/scan_split/host_path.txt); a kernel
-// whose lanes walk each (window, range) run contiguously reaches the full rate (profiles/r2_host_path_probe.txt:
-// kernels on mapped memory 55-57 GB/s) and its few waves fit beside the recurrence's on the same CUs.
-constexpr int kMaxCopyRanges = 40;
-struct CopyPlan {
-    int n = 0;
-    int a[kMaxCopyRanges];            // first column of range i
-    int cum[kMaxCopyRanges + 1];      // columns in ranges 0 .. i-1
-};
-template <int VEC>
-static __global__ __launch_bounds__(256) void k_copy_cols(const float *__restrict__ src, float *__restrict__ dst, int B, int T,
-                                                          int E, CopyPlan pl) {
-    typedef float vt __attribute__((ext_vector_type(VEC)));
-    const long per_w = (long)pl.cum[pl.n] * E / VEC;          // units per window
-    const long total = per_w * B;
-    const long stride = (long)gridDim.x * blockDim.x;
-    auto addr = [&](long i) -> size_t {
-        const long w = i / per_w;
-        const long f = (i - w * per_w) * VEC;                  // float offset inside the window's concatenated ranges
-        int r = 0;
-        while (r + 1 < pl.n && f >= (long)pl.cum[r + 1] * E) ++r;
-        return ((size_t)w * T + pl.a[r]) * E + (size_t)(f - (long)pl.cum[r] * E);
-    };
-    for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
-        size_t ad[4];
-        vt v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                          // four requests in flight per lane
-            const long i = i0 + u * stride;
-            ad[u] = i < total ? addr(i) : 0;
-            if (i < total) v[u] = *reinterpret_cast<const vt *>(src + ad[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + u * stride < total) *reinterpret_cast<vt *>(dst + ad[u]) = v[u];
     }
 }
 

@@ -207,6 +207,20 @@ class GruEngine:
                                                        pmax.ctypes.data), "mdk_gru_forward_decoded")
         return cls, pmax
 
+    def stage_input(self, x_ptr, B, T):
+        """Start the host -> device copy of a batch now (`mdk_gru_stage_input`); returns the token `forward_staged` takes."""
+        tok = ctypes.c_ulonglong(0)
+        _lib.check(_lib.load().mdk_gru_stage_input(self._h, x_ptr, int(B), int(T), ctypes.byref(tok)), "mdk_gru_stage_input")
+        return tok.value
+
+    def forward_staged(self, token, B, T, out_ptr):
+        """The forward of a staged batch; False if the token is no longer valid (then use the ordinary host forward)."""
+        rc = _lib.load().mdk_gru_forward_staged(self._h, ctypes.c_ulonglong(token), int(B), int(T), out_ptr)
+        if rc == _lib.MDK_ERR_ARG:
+            return False
+        _lib.check(rc, "mdk_gru_forward_staged")
+        return True
+
     def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
         """Raw-pointer forward: host pointers (`host=True`) or device pointers + hipStream_t."""
         L = _lib.load()

@@ -135,6 +135,8 @@ def build_commands(args, shards):
                "MEDAKA_AMD": "0" if args.reference_model else ("1" if args.lenient else "strict"),
                "MEDAKA_AMD_PROCS_PER_GPU": str(args.procs_per_gpu), "MEDAKA_AMD_SHARD": str(i),
                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        if getattr(args, "reproducible", False):
+            env["MDK_SCAN_SPLIT"] = "0"          # sequential scans: bits independent of batching, hence of the sharding
         jobs.append((env, argv, hdf))
     return jobs
 
@@ -207,6 +209,9 @@ def parse(argv=None):
     ap.add_argument("--lenient", action="store_true",
                     help="MEDAKA_AMD=1 instead of strict: a model outside the engine's envelope runs on the reference "
                          "implementation with a warning instead of stopping the job")
+    ap.add_argument("--reproducible", action="store_true",
+                    help="children run with MDK_SCAN_SPLIT=0: the sequential scan's probabilities do not depend on how windows "
+                         "are batched, so shard HDFs are bit-identical to a single-process run's (at about half the speed)")
     ap.add_argument("--dry-run", action="store_true", dest="dry_run", help="write the BED files, print the commands")
     argv = list(sys.argv[1:] if argv is None else argv)
     extra = []

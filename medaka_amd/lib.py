@@ -69,6 +69,8 @@ ABI = {
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
+    "mdk_gru_stage_input": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "mdk_gru_forward_staged": (_i, [_vp, ctypes.c_ulonglong, _i, _i, _vp]),
     "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),

@@ -10,9 +10,13 @@ This module only decides WHO takes WHICH region, and it cuts exactly where the r
 start every `bam_chunk - chunk_ovlp` bases (prediction.py:100-110 -> common.Region.split with
 fixed_size=False, common.py:711-736).  `shard_regions` hands out THOSE pieces -- each is at most
 `bam_chunk` long, so the per-GPU process does not cut it again -- which makes the set of regions, hence
-of pileups, windows and samples, identical to a single-process run: the stitched consensus of the
-joined HDFs is the same by construction (tests/test_e2e_gpu.py checks it against the reference's
-own FASTQ).  One exception is handled explicitly: a trailing piece SHORTER than `chunk_len` would, as a
+of pileups, windows and samples, identical to a single-process run.  The PROBABILITIES of a sample are
+the single-process run's to ~1e-7, not bit for bit: with the split scan on (the default) they depend at that
+level on how many windows share a batch and on the margin a model has escalated to, and a sharded run
+batches its windows differently; the stitched consensus is the same wherever the model separates its top
+two classes by more than that (tests/test_e2e_gpu.py checks a sharded run against the reference's own
+FASTQ).  Where bit-reproducibility across shardings matters, run the children with MDK_SCAN_SPLIT=0
+(`medaka_amd.launch --reproducible`): the sequential scan's bits do not depend on the batch.  One exception is handled explicitly: a trailing piece SHORTER than `chunk_len` would, as a
 region of its own, take the child's `region.size < chunk_len` branch (prediction.py:97-98: un-chunked
 remainder pass) whereas a single process keeps it in the batched pass (it is only the *contig* that is tested
 there).  Such a tail therefore travels together with its predecessor as ONE region [prev.start, end): the

@@ -34,6 +34,32 @@ def _batch_buffer(shape, dtype):
     return torch.empty(shape, dtype=dtype)
 
 
+# Early hand-over (include/medaka_amd.h `mdk_gru_stage_input`): the engine whose model will see the batches registers itself
+# here (models.GRUModel.engine()); `stack_counts` then starts the batch's host -> device copy from the Batcher thread, so
+# that it crosses PCIe while the main thread is still inside `predict_on_batch` of the previous batch.  The token rides on
+# the tensor (`_mdk_stage`); `predict_on_batch` redeems it.  MEDAKA_AMD_STAGE=0 turns it off.
+_stage_target = None
+
+
+def set_stage_target(engine):
+    """`engine`: a medaka_amd.engine.GruEngine (kept by weak reference) or None."""
+    global _stage_target
+    import weakref
+    _stage_target = weakref.ref(engine) if engine is not None else None
+
+
+def _stage(out):
+    if _stage_target is None or os.environ.get("MEDAKA_AMD_STAGE", "1") == "0" or not out.is_pinned():
+        return
+    eng = _stage_target()
+    if eng is None or out.dim() != 3 or out.shape[2] != eng.num_features:
+        return
+    try:
+        out._mdk_stage = (eng, eng.stage_input(out.data_ptr(), out.shape[0], out.shape[1]))
+    except Exception:        # staging is an optimisation: the ordinary path answers
+        pass
+
+
 def stack_counts(feats, threads=None):
     """`torch.stack([torch.from_numpy(f) for f in feats]).float()` (reference torch_ext.py:147-148) without the
     17 ms it costs per 200 x 10000 x 10 batch on one thread into fresh pageable memory: equal-shaped,
@@ -49,6 +75,7 @@ def stack_counts(feats, threads=None):
     rows = (ctypes.c_void_p * len(feats))(*[f.ctypes.data for f in feats])
     _lib.check(_lib.load().mdk_gather_rows(out.data_ptr(), rows, len(feats), first.nbytes,
                                            threads or COLLATE_THREADS), "mdk_gather_rows")
+    _stage(out)
     return out
 
 

@@ -17,7 +17,7 @@ if os.environ.get("STUB_FAIL") == os.environ["HIP_VISIBLE_DEVICES"]:
 if os.environ.get("STUB_SLOW"):
     time.sleep(float(os.environ["STUB_SLOW"]))
 json.dump({"gpu": os.environ["HIP_VISIBLE_DEVICES"], "amd": os.environ.get("MEDAKA_AMD"), "bam": bam,
-           "share": os.environ.get("MEDAKA_AMD_PROCS_PER_GPU"),
+           "share": os.environ.get("MEDAKA_AMD_PROCS_PER_GPU"), "scan_split": os.environ.get("MDK_SCAN_SPLIT"),
            "regions": regions, "args": args, "cuda_visible": os.environ.get("CUDA_VISIBLE_DEVICES")}, open(hdf, "w"))
 '''
 
@@ -101,6 +101,17 @@ def test_procs_per_gpu_shares_each_gpu_between_k_children(tmp_path, monkeypatch)
     with pytest.raises(SystemExit):                  # the cluster recurrence of rl_lstm384 cannot share its GPU
         launch.parse(["b.bam", draft, "o", "--procs-per-gpu", "2", "--model", "r1041_e82_400bps_sup_v5.2.0_rl_lstm384_dwells"])
     assert launch.parse(["b.bam", draft, "o", "--lenient"]).lenient
+
+
+def test_reproducible_children_run_sequential_scans(tmp_path, monkeypatch):
+    """`--reproducible`: children get MDK_SCAN_SPLIT=0 (the sequential scan's bits do not depend on how windows are
+    batched, so shard HDFs equal a single-process run's bit for bit); without it the variable is left alone."""
+    monkeypatch.delenv("MDK_SCAN_SPLIT", raising=False)
+    draft, stub = _setup(tmp_path)
+    for flag, want in ((["--reproducible"], "0"), ([], None)):
+        out = tmp_path / ("out" + "".join(flag))
+        assert launch.main(["calls.bam", draft, str(out), "--gpus", "2", "--inference-cmd", stub] + flag) == 0
+        assert [json.load(open(out / f"shard_{i}.hdf"))["scan_split"] for i in range(2)] == [want, want]
 
 
 def test_region_strings_follow_the_reference(tmp_path):

@@ -286,11 +286,11 @@ def test_counts_in_decoded_out_at_full_size_through_the_split_scan(gold):
 
 @pytest.mark.parametrize("B,T", [(200, 10000), (100, 10000), (10, 10000), (37, 9999), (3, 3073), (1, 10000)])
 def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
-    """`mdk_gru_forward` of a split call with PAGE-LOCKED buffers (what `predict_on_batch` hands over): x comes in and the
-    probabilities leave in column slabs under the recurrences, through copy kernels on the buffers' device-visible
-    addresses (api.hip run_split / forward_pass HostIO).  Only data movement and the cut of the scans into resumed
-    launches differ: the bits must be those of the device entry and of the one-copy-each-way path (pageable buffers,
-    or option "stream_host" = 0) -- pinned in / pageable out and the reverse included."""
+    """`mdk_gru_forward` of a split call.  With option "stream_host" = 2 the probabilities leave in column chunks (2-D DMA
+    copies) behind the classifier head, under the tail of the last recurrence (api.hip run_split / forward_pass HostIO),
+    page-locked or pageable buffers alike -- measured a small loss, so not the default, but it must stay correct: only
+    data movement and the cut of the last scan into resumed launches differ, the bits must be those of the device entry
+    and of the default path (one copy each way).  A batch handed over early (`mdk_gru_stage_input`) gives the same bits."""
     x = synth.counts_windows(B, T, depth=40, seed=11 * B + T)
     e = engine.GruEngine(gold["weights_trained"])
     e.enable_timing(True)
@@ -301,28 +301,78 @@ def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
     info = e.split()
     assert info["status"] == "certified", info
     want = yd.cpu().numpy()
-    plain = e.forward_host(x)                                  # pageable in, pageable out
+    streamable = e.split()["columns"] >= 512
+    plain = e.forward_host(x)                                  # pageable in, pageable out; default: one copy each way
     assert e.timing()["host_streamed"] == 0 and np.array_equal(plain, want)
     pin_x, pin_p = engine.PinnedArray(x.shape), engine.PinnedArray(want.shape)
     pin_x.array[...] = x
-    streamable = e.split()["columns"] >= 512
-    for rep in range(3):                                       # repeated: the slabs land in recycled buffers
+    e.set_option("stream_host", 2)                             # the result leaves chunk by chunk behind the head
+    for rep in range(3):                                       # repeated: the chunks land in a recycled buffer
         pin_p.array[...] = -1.0
         out = e.forward_host(pin_x.array, out=pin_p.array)
-        assert e.timing()["host_streamed"] == (3 if streamable else 0), (e.timing(), e.split())
+        assert e.timing()["host_streamed"] == (2 if streamable else 0), (e.timing(), e.split())
         assert np.array_equal(out, want), (rep, float(np.abs(out - want).max()))
-    assert np.array_equal(e.forward_host(pin_x.array), want) and e.timing()["host_streamed"] == (1 if streamable else 0)
-    pin_p.array[...] = -1.0
-    assert np.array_equal(e.forward_host(x, out=pin_p.array), want) and e.timing()["host_streamed"] == (2 if streamable else 0)
-    e.set_option("stream_host", 0)
-    assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), want) and e.timing()["host_streamed"] == 0
+    assert np.array_equal(e.forward_host(x), want)             # ... into pageable memory as well
     e.set_option("stream_host", 1)
+    pin_p.array[...] = -1.0
+    assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), want) and e.timing()["host_streamed"] == 0
+    # early hand-over (mdk_gru_stage_input / mdk_gru_forward_staged): same bits, no input copy inside the call
+    tok = e.stage_input(pin_x.array.ctypes.data, B, T)
+    pin_p.array[...] = -1.0
+    assert e.forward_staged(tok, B, T, pin_p.array.ctypes.data) and np.array_equal(pin_p.array, want)
+    assert e.timing()["host_streamed"] & 4
+    assert not e.forward_staged(tok, B, T, pin_p.array.ctypes.data)           # a token is good for one forward
+    n_slots = 12 if B * T <= 400000 else 3                                      # (keep the big shapes cheap)
+    toks = [e.stage_input(pin_x.array.ctypes.data, B, T) for _ in range(n_slots + (1 if n_slots == 12 else 0))]
+    if n_slots == 12:
+        assert not e.forward_staged(toks[0], B, T, pin_p.array.ctypes.data)    # twelve slots: the thirteenth pushes the first out
+        toks = toks[1:]
+    for t in toks:
+        pin_p.array[...] = -1.0
+        assert e.forward_staged(t, B, T, pin_p.array.ctypes.data) and np.array_equal(pin_p.array, want)
     # a view into a larger page-locked block at an odd float offset (4-byte aligned only): scalar copies, same bits
     big = engine.PinnedArray((x.size + 3,))
     big.array[1:1 + x.size] = x.ravel()
     odd = big.array[1:1 + x.size].reshape(x.shape)
     assert np.array_equal(e.forward_host(odd, out=pin_p.array), want)
     e.close()
+
+
+def test_collated_batches_are_handed_over_early(gold):
+    """The engine's `Batch.collate` (installed over the reference's by `integration.install`) starts the batch's host ->
+    device copy from the thread that assembles it; `predict_on_batch` redeems the token the tensor carries.  Same bits as
+    the ordinary path; a batch collated in another thread (the reference's Batcher, prediction.py:356-370) as well; a
+    Batch reused for a second call, or built by hand, takes the ordinary path."""
+    import threading
+
+    class S:
+        def __init__(self, f):
+            self.features = f
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    m = m.to("cuda").eval()
+    eng = m.engine()                                           # registers the engine as the collate's staging target
+    eng.enable_timing(True)
+    xs = [synth.counts_windows(24, 4096, depth=40, seed=60 + i) for i in range(3)]
+    want = [eng.forward_host(x) for x in xs]
+    for x, w in zip(xs, want):
+        b = Batch.collate([S(r) for r in x])
+        assert b.counts_matrix.is_pinned() and getattr(b.counts_matrix, "_mdk_stage", None) is not None
+        assert np.array_equal(m.predict_on_batch(b).numpy(), w) and eng.timing()["host_streamed"] & 4
+        assert np.array_equal(m.predict_on_batch(b).numpy(), w) and not eng.timing()["host_streamed"] & 4     # token spent
+    box = {}
+    t = threading.Thread(target=lambda: box.update(b=Batch.collate([S(r) for r in xs[1]])))
+    t.start(); t.join()
+    assert np.array_equal(m.predict_on_batch(box["b"]).numpy(), want[1]) and eng.timing()["host_streamed"] & 4
+    by_hand = Batch(counts_matrix=torch.from_numpy(xs[2]))
+    assert np.array_equal(m.predict_on_batch(by_hand).numpy(), want[2]) and not eng.timing()["host_streamed"] & 4
+    os.environ["MEDAKA_AMD_STAGE"] = "0"
+    try:
+        b = Batch.collate([S(r) for r in xs[0]])
+        assert getattr(b.counts_matrix, "_mdk_stage", None) is None
+        assert np.array_equal(m.predict_on_batch(b).numpy(), want[0])
+    finally:
+        del os.environ["MEDAKA_AMD_STAGE"]
 
 
 def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
