@@ -69,7 +69,7 @@ def parse():
                          "`value` / `host_to_host` are the aggregates of the K processes, `n_gpus` counts the ranks")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
-    ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default) or one copy each side (0)")
+    ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default), one copy each side (0), 2 = also a split call's result")
     ap.add_argument("--pinned-input", action="store_true",
                     help="host-to-host batches from a page-locked input tensor (what medaka_amd's Batch.collate produces)")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")

@@ -70,7 +70,8 @@ typedef struct {
                              tail of the last recurrence ("stream_host" = 2; else one copy after the forward); bit 2 = x had
                              been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call) */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
-                             "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both) */
+                             "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both); bit 8: the classifier's Linear
+                             ran inside the last layer's kernel as well ("fuse_head": head_ms is the combine kernel) */
 } mdk_gru_timing;
 
 /* What the last forward did about splitting the scan (option "scan_split" below). */
@@ -153,6 +154,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   (bit-identical to the separate GEMM; fp32-parity mode, 8-window
  *                                                   work-groups, T % 8 == 0; auto: when the call fills the chip, i.e.
  *                                                   whenever "overlap_gemm" would not apply; environment MDK_FUSE_PROJ)
+ *   "fuse_head"            = 1 | 0                  with a fused last layer: Linear(D*128 -> 5) inside its kernel as well
+ *                                                   (fp16x2-split MFMA on the h image already in LDS; the logits agree with
+ *                                                   the fp32 FMA head to ~1e-7, not bit for bit; environment MDK_FUSE_HEAD)
  *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)

@@ -64,6 +64,10 @@ struct mdk_gru {
     int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
     size_t max_rows_per_pass = 0;   // 0 = kMaxRowsPerPass
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
+    int opt_fuse_head = 1;      // last layer with a fused projection: Linear(D*128 -> 5) inside the recurrence kernel too (rec_fused.hpp HEAD)
+    half8 *wlin_frag = nullptr; // [D][4 ksteps][2 hi/lo][64 lanes] B-fragments of linear.weight (classes padded to 16 columns)
+    float lin_inv_scale = 1.f;  // 1 / (kActScale * their operand scale)
+    float *lpart = nullptr;     // partial logits of the fused head [D][n_tiles][T][8][5]
     int opt_fuse_proj = 1;      // layers >= 1: projection fused into the recurrence (rec_fused.hpp): 0 off, 1 when the call fills the chip, 2 always
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
@@ -134,6 +138,7 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
         free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
         free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.wx_frag); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
     }
+    free_dev(m->wlin_frag); free_dev(m->lpart);
     free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
     free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
     free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
@@ -314,11 +319,34 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         std::vector<float> lb(weights[4 * L * D + 1], weights[4 * L * D + 1] + C);
         if ((rc = upload(&m->lin_w, lw))) return bail(rc);
         if ((rc = upload(&m->lin_b, lb))) return bail(rc);
+        // fused head (rec_fused.hpp HEAD): B-fragments of W_lin per direction, k = hidden unit in the A image's order
+        // (slot (ks, lane-group gq, i) = unit 32 ks + 8 gq + i), column n = class (columns 5..15 zero)
+        const float swl = pick_scale(lw.data(), lw.size());
+        m->lin_inv_scale = 1.0f / (kActScale * swl);
+        std::vector<half8> wl((size_t)D * 4 * 2 * 64);
+        for (int d = 0; d < D; ++d)
+            for (int ks = 0; ks < 4; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = lane & 15, gq = lane >> 4;
+                    half8 hi, lo;
+                    for (int i = 0; i < 8; ++i) {
+                        const int u = 32 * ks + 8 * gq + i;
+                        _Float16 a = (_Float16)0.f, b = (_Float16)0.f;
+                        if (n < C) split_host(lw[(size_t)n * D * H + (size_t)d * H + u] * swl, a, b);
+                        hi[i] = a; lo[i] = b;
+                    }
+                    wl[((size_t)(d * 4 + ks) * 2 + 0) * 64 + lane] = hi;
+                    wl[((size_t)(d * 4 + ks) * 2 + 1) * 64 + lane] = lo;
+                }
+        if ((rc = upload(&m->wlin_frag, wl))) return bail(rc);
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
+    if (const char *e = getenv("MDK_FUSE_HEAD")) m->opt_fuse_head = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_FUSE_PROJ")) m->opt_fuse_proj = std::min(std::max(atoi(e), 0), 2);
 
     *out = m;
@@ -355,6 +383,8 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_ablate = value;
     } else if (!strcmp(key, "fuse_l0")) {
         m->opt_fuse_l0 = value ? 1 : 0;
+    } else if (!strcmp(key, "fuse_head")) {
+        m->opt_fuse_head = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_proj")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "fuse_proj must be 0 (off), 1 (auto) or 2 (always)");
         m->opt_fuse_proj = value;
@@ -421,13 +451,14 @@ static const size_t kMaxRowsPerPass = (size_t)16 << 20;
 
 static int ensure_workspace(mdk_gru *m, size_t rows) {
     if (rows <= m->ws_rows) return MDK_OK;
-    free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
-    m->gi = m->act[0] = m->act[1] = nullptr;
+    free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]); free_dev(m->lpart);
+    m->gi = m->act[0] = m->act[1] = m->lpart = nullptr;
     m->ws_rows = 0;
     const size_t D = m->D;
     HIP_TRY(hipMalloc((void **)&m->gi, D * rows * kG * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&m->act[0], rows * D * kH * sizeof(float)));
     if (m->desc.num_layers > 1) HIP_TRY(hipMalloc((void **)&m->act[1], rows * D * kH * sizeof(float)));
+    if (m->desc.num_layers > 1) HIP_TRY(hipMalloc((void **)&m->lpart, rows * D * 5 * sizeof(float)));
     m->ws_rows = rows;
     return MDK_OK;
 }
@@ -582,8 +613,18 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
 #undef MDK_GEMM
     };
     // classifier head over the columns [t0, t0 + nt) of every window
+    bool fuse_head = false;             // (decided below, once the overlap plan is known)
     auto launch_head = [&](const float *src, hipStream_t st, int t0, int nt) {
         if (nt <= 0) return;
+        if (fuse_head) {
+            const long n = (long)n_tiles * nt * kTileWin;
+            const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 256 * 8);
+            if (sp) hipLaunchKernelGGL(k_head_combine<true>, dim3(blocks), dim3(256), 0, st, (const float *)m->lpart, m->lin_b, probs, nb, T,
+                                       n_tiles, D, m->desc.normalise, t0, nt, *sp);
+            else hipLaunchKernelGGL(k_head_combine<false>, dim3(blocks), dim3(256), 0, st, (const float *)m->lpart, m->lin_b, probs, nb, T,
+                                    n_tiles, D, m->desc.normalise, t0, nt, SplitPlan{});
+            return;
+        }
         const long n_blocks = (long)n_tiles * nt;
         const long blocks = std::min<long>((n_blocks + 3) / 4, 256 * 8);
         if (sp)       // (plan_split: bidirectional models only)
@@ -619,6 +660,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const bool fuse_proj = L >= 2 && !hp && nq == 2 && !ablated && T % kFusedSteps == 0 &&
                            (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && !overlap_ok));
     const bool overlap = overlap_ok && !fuse_proj;
+    // ... and with it the classifier's Linear (rec_fused.hpp HEAD): the last layer leaves partial logits, k_head_combine
+    // finishes them (fp16x2-split MFMA instead of fp32 FMAs: ~1e-7 relative on the logits, not bit for bit)
+    fuse_head = fuse_proj && m->opt_fuse_head && m->desc.num_classes == 5;
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
     const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
     const bool stream_out = ((io_out && can_chunk) || (sp_out && can_chunk_sp)) && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
@@ -707,14 +751,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         // production instantiations
         auto launch = [&](bool xin, const int *cnd, int want) {
             if (fused_proj) {
-                if (D == 2)
-                    hipLaunchKernelGGL((k_rec_fused<8>), rgrid, dim3(512), fused_lds_bytes(8), s, in, Ld.wih_frag, Ld.bias_gi,
-                                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi,
-                                       Ld.up_scale_rec, kActScale, reverse_mask, rs0, rns);
-                else
-                    hipLaunchKernelGGL((k_rec_fused<4>), rgrid, dim3(512), fused_lds_bytes(4), s, in, Ld.wih_frag, Ld.bias_gi,
-                                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi,
-                                       Ld.up_scale_rec, kActScale, reverse_mask, rs0, rns);
+                const bool hd = fuse_head && l == L - 1;
+#define MDK_LAUNCH_FUSED(KS, HD)                                                                                              \
+    hipLaunchKernelGGL((k_rec_fused<KS, HD>), rgrid, dim3(512), fused_lds_bytes(KS), s, in, Ld.wih_frag, Ld.bias_gi,          \
+                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi, Ld.up_scale_rec,       \
+                       kActScale, reverse_mask, rs0, rns, (const half8 *)m->wlin_frag, m->lin_inv_scale, m->lpart)
+                if (D == 2) { if (hd) MDK_LAUNCH_FUSED(8, true); else MDK_LAUNCH_FUSED(8, false); }
+                else { if (hd) MDK_LAUNCH_FUSED(4, true); else MDK_LAUNCH_FUSED(4, false); }
+#undef MDK_LAUNCH_FUSED
+                if (hd) m->last.fused_layers |= 1 << 8;
                 m->last.fused_layers |= 1 << l;
                 return;
             }

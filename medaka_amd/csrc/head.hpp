@@ -165,6 +165,56 @@ __global__ __launch_bounds__(256) void k_head_tiled(
     }
 }
 
+// Head of a last layer whose Linear ran inside the recurrence kernel (rec_fused.hpp HEAD): lpart holds, per direction,
+// the 5 partial logits of the 8 windows of every (tile, t) block.  logits = part_0 (+ part_1) + bias, softmax as above,
+// probabilities out in the reference's natural (B, T, 5) order; SPLIT as in k_head_tiled.  One thread per (block, window).
+template <bool SPLIT>
+static __global__ __launch_bounds__(256) void k_head_combine(
+    const float *__restrict__ lpart,  // [D][n_tiles][T][8][5]
+    const float *__restrict__ lin_b,  // [5]
+    float *__restrict__ probs, int B, int T, int n_tiles, int D, int normalise, int t0, int nt, SplitPlan sp)
+{
+    const long total = (long)n_tiles * nt * kTileWin;
+    const size_t dir_stride = (size_t)n_tiles * T * 40;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i & 7);
+        const long blk = i >> 3;
+        const int tile = (int)(blk / nt), t = t0 + (int)(blk % nt);
+        const int win = tile * kTileWin + w;
+        if (win >= B) continue;
+        float *dst = probs + ((size_t)win * T + t) * 5;
+        if constexpr (SPLIT) {
+            const int k = win / sp.B, tr = sp.start[k] + t;
+            if (tr < sp.core0[k] || tr >= sp.core0[k + 1]) continue;
+            dst = probs + ((size_t)(win - k * sp.B) * sp.T + tr) * 5;
+        }
+        const float *src = lpart + ((size_t)tile * T + t) * 40 + w * 5;
+        float acc[5];
+#pragma unroll
+        for (int cl = 0; cl < 5; ++cl) {
+            float v = src[cl];
+            if (D == 2) v += src[dir_stride + cl];
+            acc[cl] = v + lin_b[cl];
+        }
+        float res[5];
+        if (normalise) {
+            float mx = acc[0];
+#pragma unroll
+            for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, acc[cl]);
+            float sum = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) { res[cl] = __expf(acc[cl] - mx); sum += res[cl]; }
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) res[cl] = res[cl] / sum;
+        } else {
+#pragma unroll
+            for (int cl = 0; cl < 5; ++cl) res[cl] = acc[cl];
+        }
+#pragma unroll
+        for (int cl = 0; cl < 5; ++cl) dst[cl] = res[cl];
+    }
+}
+
 // channels a c g t A C G T d D -> classes [d+D, a+A, c+C, g+G, t+T]; class 0 += 1 - sum
 static __global__ __launch_bounds__(256) void k_majority(const float *__restrict__ x,
                                                   float *__restrict__ probs, long n_cols)

@@ -24,6 +24,17 @@
 // HBM per column and direction: 1024 B of activations in (both input directions) + 512 B of h out, against
 // 512 + 1536 (GEMM, its share) + 1536 + 512 (recurrence).
 // fp32-parity mode (fp16 hi/lo split), 8-window work-groups, GRU cell; T, s0, ns multiples of 8.
+//
+// HEAD (last layer): the classifier's Linear(D*128 -> 5) is fused as well.  The fp16 hi/lo image of h_t that every step
+// publishes in LDS for the next step IS the A operand of  logits_d[t] = h_d[t] W_lin[:, d*128 : d*128+128]^T ; with HEAD the
+// images of a strip's 8 steps stay in an 8-slot ring, and at the start of the next projection phase wave j multiplies
+// step j's image by the 8 W_lin fragments (4 k-steps x hi/lo: 8 MFMAs per wave and strip against 288 of projection) and
+// stores this direction's 5 partial logits of its 8 windows (160 bytes per (tile, t, direction)).  k_head_combine
+// (head.hpp) adds the two directions and the bias and takes the softmax: a 40-us kernel instead of the 0.41 ms
+// k_head_tiled pass over the activations -- and, unlike that one, small enough to run beside a recurrence that holds
+// every CU, which is what lets the host path send finished columns home while the scan is still running.
+// Same fp16x2 split as everywhere (h hi+lo times W hi+lo, fp32 accumulate): logits agree with the fp32 FMA head to ~1e-7
+// relative, not bit for bit.
 #pragma once
 #include "common.hpp"
 #include "gi_proj.hpp"
@@ -36,7 +47,7 @@ constexpr int kFusedSteps = 8;                         // scan steps per strip =
 constexpr int kFusedMT = kFusedSteps / 2;
 __host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS) { return (size_t)2 * kFusedMT * KSTEPS * 64 * 16; }
 
-template <int KSTEPS>   // K = 32 * KSTEPS = DIN * 128 input features
+template <int KSTEPS, bool HEAD>   // K = 32 * KSTEPS = DIN * 128 input features
 __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const float *__restrict__ act_in,   // act_t of the previous layer (|x| < 1)
     const half8 *__restrict__ wihfrag,  // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]   (as k_gi_gemm)
@@ -47,7 +58,10 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     int n_tiles, int T, int D,
     const float *__restrict__ inv_scale_rec_p, const float *__restrict__ inv_scale_gi_p,
     const float *__restrict__ up_scale_rec_p, float a_scale,
-    int reverse_mask, int s0, int ns)
+    int reverse_mask, int s0, int ns,
+    const half8 *__restrict__ wlin_frag,   // HEAD: W_lin B-fragments [D][4 ksteps][2 hi/lo][64 lanes] (column n = class, n >= 5 zero)
+    float lin_inv_scale,                   // HEAD: 1 / (kActScale * W_lin's operand scale)
+    float *__restrict__ lpart)             // HEAD: partial logits [D][n_tiles][T][8 windows][5]
 {
     constexpr int DIN = KSTEPS / 4;
     constexpr int NP = DIN * 128;               // 8-float pieces per activation block
@@ -56,7 +70,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     static_assert(NPIECE == 2 || NPIECE == 4, "staging schedule below assumes 2 or 4 pieces per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *xs = reinterpret_cast<half8 *>(smem);            // [split 2][mt MT][KSTEPS][64 lanes]
-    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * kHBufBytes];
+    constexpr int NIMG = HEAD ? 8 : 2;      // images of h kept: the step's two, or a whole strip's for the head
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[NIMG * kHBufBytes];
     __builtin_amdgcn_s_setprio(MDK_REC_PRIO);
 
     const int tid = threadIdx.x;
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
-    for (int i = tid; i < 2 * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+    for (int i = tid; i < NIMG * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
 
     const int u = 16 * w8 + c;
     const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             hprev[q] = h;
             _Float16 hi, lo;
             split_f16(h * kActScale, hi, lo);
-            unsigned char *img = hbuf + (s0 & 1) * kHBufBytes + wr_off;
+            unsigned char *img = hbuf + (s0 & (NIMG - 1)) * kHBufBytes + wr_off;
             *reinterpret_cast<_Float16 *>(img + (2 * q) * 16) = hi;
             *reinterpret_cast<_Float16 *>(img + (2 * q + 1) * 16) = lo;
         }
@@ -171,7 +186,28 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 
     const half8 *wp = wihfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
 
+    // HEAD: partial logits of strip `hs`, one scan step per wave (the image of h after step s sits in slot (s + 1) % 8)
+    auto head_strip = [&](int hs) {
+        const int s = hs * kFusedSteps + w8;
+        const int t = reverse ? (T - 1 - s) : s;
+        const unsigned char *img = hbuf + ((w8 + 1) & 7) * kHBufBytes + rd_off;
+        const half8 *wl = wlin_frag + (size_t)d * 8 * 64 + lane;
+        floatx4 la = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 a = *reinterpret_cast<const half8 *>(img + ks * kHKStride);
+            la = mfma16(a, wl[(size_t)(ks * 2 + 0) * 64], la);
+            la = mfma16(a, wl[(size_t)(ks * 2 + 1) * 64], la);
+        }
+        if (c < 5) {
+            float *dst = lpart + (((size_t)d * n_tiles + tile) * T + t) * 40 + (2 * g) * 5 + c;
+            dst[0] = (la[0] + la[1]) * lin_inv_scale;      // window 2g:     hi row + lo row
+            dst[5] = (la[2] + la[3]) * lin_inv_scale;      // window 2g + 1
+        }
+    };
+
     for (int strip = strip0; strip < strip1; ++strip) {
+        if constexpr (HEAD) { if (strip > strip0) head_strip(strip - 1); }
         // ================= projection phase: gi of this strip into acc (k_gi_gemm inner loop, this direction only)
         floatx4 acc[MT][3];
 #pragma unroll
@@ -218,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
         for (int j = 0; j < kFusedSteps; ++j) {
             const int step = strip * kFusedSteps + j;
-            const int cur = (step & 1) * kHBufBytes;
-            const int nxt = kHBufBytes - cur;
+            const int cur = (step & (NIMG - 1)) * kHBufBytes;
+            const int nxt = ((step + 1) & (NIMG - 1)) * kHBufBytes;
             constexpr int kIssue = NPIECE == 4 ? 1 : 2;      // a piece is requested every kIssue steps, stored 2 steps later
             half8 a[4];
 #pragma unroll
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) *(op[q] - ostride) = hprev[q];      // the last step's h
+    if constexpr (HEAD) head_strip(strip1 - 1);                      // (the last step's barrier made its image visible)
 }
 
 }  // namespace mdk

@@ -289,6 +289,7 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
     e = engine.GruEngine(st, **kw)
     e.enable_timing(True)
     e.set_option("rec_windows_per_tile", 8)          # the fused kernel carries 8 windows per work-group
+    e.set_option("fuse_head", 0)                      # (the fused classifier head is ~1e-7, not bitwise: checked below)
     n = 0
     for B, T in ((13, 2304), (9, 8), (8, 16), (3, 1000), (40, 264), (17, 4096), (5, 999)):
         x = synth.counts_windows(B, T, depth=40, seed=B * 1000 + T)
@@ -303,6 +304,26 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
         if bidirectional:
             _check(outs[2], oracle.c_gru_forward(x, st) if B * T < 40000 else outs[0], what=f"fused {B}x{T}")
     assert n >= 5
+    # the classifier's Linear inside the last layer's kernel (rec_fused.hpp HEAD) + k_head_combine: fp16x2-split MFMA
+    # instead of fp32 FMAs, so ~1e-7 on the probabilities instead of identical bits; whole and resumed layers
+    e.set_option("fuse_proj", 2)
+    for B, T in ((13, 2304), (9, 8), (3, 1000), (17, 4096)):
+        x = synth.counts_windows(B, T, depth=40, seed=B * 1000 + T)
+        e.set_option("fuse_head", 0)
+        plain = e.forward_host(x)
+        e.set_option("fuse_head", 1)
+        fused = e.forward_host(x)
+        assert e.timing()["fused_layers"] == (2 | 256), e.timing()
+        d = float(np.abs(fused - plain).max())
+        assert d <= 1e-6, (B, T, d)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.empty(B, T, 5, device="cuda")
+        e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), fused)            # one launch per layer == resumed launches, bit for bit
+        if bidirectional and B * T < 40000:
+            _check(fused, oracle.c_gru_forward(x, st), what=f"fused head {B}x{T}")
+    e.set_option("fuse_head", 0)
     # auto mode: small batches leave CUs idle and keep the GEMM on the side stream; batches that fill the chip fuse
     e.set_option("rec_windows_per_tile", 0)
     e.set_option("fuse_proj", 1)
@@ -313,6 +334,10 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
     assert e.timing()["fused_layers"] == 2
     e.set_option("fuse_proj", 0)
     assert np.array_equal(e.forward_host(x), out)
+    e.set_option("fuse_proj", 1)
+    e.set_option("fuse_head", 1)                      # the product default
+    out_h = e.forward_host(x)
+    assert e.timing()["fused_layers"] == (2 | 256) and np.abs(out_h - out).max() <= 1e-6
     e.close()
 
 
