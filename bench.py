@@ -70,9 +70,13 @@ def parse():
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
     ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default), one copy each side (0), 2 = also a split call's result")
-    ap.add_argument("--pinned-input", action="store_true",
-                    help="host-to-host batches from a page-locked input tensor (what medaka_amd's Batch.collate produces)")
+    ap.add_argument("--pinned-input", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--pageable-input", action="store_true",
+                    help="host-to-host batches only from a pageable input tensor (the reference's collate) instead of the page-locked "
+                         "one the engine's Batch.collate produces")
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
+    ap.add_argument("--extra-rl", type=float, default=15.0,
+                    help="seconds of CPU baseline granted to the rl_lstm384 line that the default run appends under `extra` (0 = no extra line)")
     ap.add_argument("--loop-batches", type=int, default=14,
                     help="batches of the fed loop (threaded loader -> collate -> predict_on_batch -> writer; 0 = skip)")
     return ap.parse_args()
@@ -150,10 +154,12 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
     base = {"value": best["columns_per_s"], "unit": "pileup columns/s", "cores": best["threads"], "kind": kind,
             "host_cores_available": cores, "os_cpu_count": os.cpu_count(), "table": table, "not_run": skipped,
             "wall_clock_cap_s": budget_s,
+            "passes": best["passes"],
             "sample": f"best of the BASELINE.md section-4 grid that fits {budget_s:.0f} s: B={best['batch']} x {T} columns, "
-                      f"{best['threads']} torch threads, fp32 PyTorch-CPU "
-                      + ("(unmodified reference GRUModel.predict_on_batch)" if kind == "reference" else
-                         "(nn.GRU+Linear+softmax, the ops of reference gru.py:66-71)")}
+                      f"{best['threads']} torch threads, fp32 PyTorch-CPU, median of {best['passes']} timed pass(es) after a warm-up; kind = "
+                      + ("reference: the unmodified reference GRUModel.predict_on_batch (/root/reference present)" if kind == "reference" else
+                         "port: the three torch calls of reference gru.py:66-71 restated (nn.GRU + Linear + softmax; /root/reference does not "
+                         "exist on the GPU box)")}
     n = ref.shape[0]
     parity = {"max_abs_dp": float(np.abs(probs_sample[:n] - ref).max()),
               "argmax_identical": bool((probs_sample[:n].argmax(-1) == ref.argmax(-1)).all()),
@@ -310,6 +316,83 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
     return out
 
 
+
+MFMA_FLOP = 2 * 16 * 16 * 32        # one v_mfma_f32_16x16x32_f16
+SUSTAINED_MFMA_FRACTION = 0.66      # of the nominal issue rate over tens of seconds on this chip (profiles/probes/mfma_burn.hip: 0.64-0.67)
+
+
+def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families=None):
+    """One entry per hot kernel family of the consensus forward: milliseconds per step (hipEvents on the engine's streams),
+    algorithmic FLOP (the network's own MACs on the REAL columns), issued FLOP (every MFMA the kernels execute: split
+    products, the hi|lo row padding, the margin columns of a split scan), both as a fraction of the 2.5 PFLOP/s fp16 dense
+    peak, and the HBM rate the kernel's algorithmic bytes imply.  The step-level figures use the device-resident total."""
+    rec0, rec1, gi, head, total = (statistics.mean(v) if v else 0.0 for v in timing_lists)
+    cols = B * T
+    vcols = split["chunks"] * B * split["columns"] if split["chunks"] > 1 else cols       # columns the kernels really scan
+    vwin = split["chunks"] * B if split["chunks"] > 1 else B
+    nq = 2 if (-(-vwin // 4)) * 2 > 232 else 1          # the engine's work-group rule (api.hip): 8-window groups once 4-window ones overflow the chip
+    if half:
+        nq = 1 if (-(-vwin // 4)) * 2 <= 232 else (2 if (-(-vwin // 8)) * 2 <= 232 else 4)
+    wg_cols = vcols / (4.0 * nq) * 2                    # (work-group, step) pairs of one layer: both directions
+    prod = 1 if half else 2                             # MFMAs per (k-step, gate): W_hi and W_lo passes (the hi|lo rows ride along)
+    proj_prod = 1 if half else 3
+    fused1, fused_head = bool(fused_layers & 2), bool(fused_layers & 256)
+    k = []
+    def entry(name, ms, algo_mac, mfma, hbm_bytes, note):
+        if ms <= 0:
+            return
+        algo, issued = 2.0 * algo_mac * cols, mfma * MFMA_FLOP
+        k.append({"kernel": name, "ms_per_step": ms, "algorithmic_gflop": algo / 1e9, "issued_gflop": issued / 1e9,
+                  "algorithmic_tflops": algo / ms / 1e9, "frac_algorithmic_of_fp16_peak": algo / ms / 1e9 / PEAK_F16_DENSE_TFLOPS,
+                  "frac_issued_of_fp16_peak": issued / ms / 1e9 / PEAK_F16_DENSE_TFLOPS,
+                  "hbm_algorithmic_gb": hbm_bytes / 1e9, "hbm_gb_per_s": hbm_bytes / ms / 1e6, "note": note})
+    entry("k_rec_mfma<XIN> (layer 0: recurrence + fused K=10 projection; k_pack_x inside its span)", rec0, 98304 + 7680,
+          wg_cols * 8 * (12 * prod + 3 * prod), vcols * (1024 + 1024 / (4 * nq)) + vcols * (40 + 1024 / (4 * nq)),
+          "8 waves x (24 + 6) MFMAs per work-group and step")
+    if fused1:
+        entry("k_rec_fused (layer 1: K=256 projection + recurrence" + (" + classifier Linear" if fused_head else "") + " in one kernel)", rec1,
+              98304 + 196608 + (1280 if fused_head else 0), wg_cols * 8 * (12 * prod + 12 * proj_prod + (1 if fused_head else 0)),
+              vcols * (2048 + 1024 + (40 if fused_head else 0)),
+              "per work-group and strip of 8 steps: 8 waves x (288 projection + 8 x 24 recurrence" + (" + 8 head" if fused_head else "") + ") MFMAs; gi never in HBM")
+    else:
+        entry("k_rec_mfma (layer 1 recurrence)", rec1, 98304, wg_cols * 8 * 12 * prod, vcols * 4096, "reads gi (3072 B/column), writes h")
+        entry("k_gi_gemm (layer 1 projection)", gi, 196608, vcols / 64.0 * 8 * 96 * proj_prod * 2, vcols * 4096, "writes gi as fp32: 3072 B/column")
+    entry("k_head_combine (bias + softmax of the partial logits)" if fused_head else "k_head_tiled (Linear + softmax)", head,
+          0 if fused_head else 1280, 0, (vcols * 40 + cols * 20) if fused_head else (vcols * 1024 + cols * 20), "HBM streaming")
+    issued_total = sum(e["issued_gflop"] for e in k)
+    step = {"device_total_ms": total, "algorithmic_gflop": FLOP_PER_COLUMN * cols / 1e9, "issued_gflop": issued_total,
+            "frac_algorithmic_of_fp16_peak": FLOP_PER_COLUMN * cols / total / 1e9 / PEAK_F16_DENSE_TFLOPS if total else None,
+            "frac_issued_of_fp16_peak": issued_total / total / PEAK_F16_DENSE_TFLOPS if total else None,
+            "frac_issued_of_sustained_rate": issued_total / total / (PEAK_F16_DENSE_TFLOPS * SUSTAINED_MFMA_FRACTION) if total else None,
+            "sustained_rate_note": f"a register-only MFMA loop on every SIMD sustains {SUSTAINED_MFMA_FRACTION:.2f} of the nominal rate over tens of "
+                                   "seconds on this chip (power management; profiles/probes/mfma_burn.hip, profiles/r3_experiments/README.md)",
+            "virtual_columns_scanned": vcols, "real_columns": cols, "windows_per_work_group": 4 * nq}
+    if traffic_families:
+        for e in k:
+            for fam, rec in traffic_families.items():
+                if fam.split("<")[0] in e["kernel"] and rec.get("hbm_bytes_per_step") and ("XIN=1" in fam) == ("XIN" in e["kernel"]):
+                    e["hbm_measured_gb"] = rec["hbm_bytes_per_step"] / 1e9
+    return k, step
+
+def pmc_summary_r4(name="r4_pmc_step.csv"):
+    """Matrix-pipe busy share and HBM rate per kernel family from the committed counter summary of THIS build at 200 x 10000
+    (profiles/r4_pmc_step.csv: rocprofv3 --pmc passes of `bench.py --device-only --steps 1`, summed over the step by
+    profiles/pmc_step.py).  SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs."""
+    import csv
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        acc = {}
+        for row in csv.DictReader(open(path)):
+            acc.setdefault(row["kernel_family"], {})[row["counter"]] = float(row["sum_over_step"])
+        out = {"source": f"profiles/{name}"}
+        for fam, c in acc.items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+                out[fam] = {"mfma_busy_of_chip": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)}
+        return out
+    except Exception as exc:
+        return {"error": str(exc)}
+
+
 RL_CONV2_FLOP = 2 * 128 * 128 * 17      # per (window, read, position): Conv1d(128 -> 128, k = 17), the bulk of k_rl_front
 
 
@@ -353,7 +436,7 @@ def rl_traffic(model, B, P, D):
         return None
 
 
-def main_rl(args):
+def main_rl(args, emit=True):
     """BASELINE config 4b: the read-level model (reference LatentSpaceLSTM) over uint8 read matrices, one GPU
     per rank, input resident in HBM.  rl384 = the bundled rl_lstm384 architecture (lstm 384, 4 x uni-directional,
     dwells), weights from a seed (20 MB, not committed); rl128 = class defaults, committed trained-like weights."""
@@ -427,6 +510,19 @@ def main_rl(args):
                      "kernel_ms_per_step": {"front": statistics.mean(front), "device_total": statistics.mean(total)},
                      "wide_retries": eng.timing()["wide_retries"]},
     }
+    # host tensor in -> host tensor out, as the prediction loop calls it
+    from medaka_amd.torch_ext import Batch
+    xb = Batch(read_level_features=x.cpu())
+    h2h = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        m.predict_on_batch(xb)
+        h2h.append(time.perf_counter() - t0)
+    h_med = ranks.max_over_ranks(statistics.median(h2h[1:]))
+    result["host_to_host"] = {"value": ranks.world * cols / h_med, "unit": "pileup columns/s", "ms_per_batch_median": 1e3 * h_med,
+                              "timed_batches": 3, "frac_of_device_resident": (cols / h_med) / (value / ranks.world),
+                              "what": f"model.predict_on_batch(Batch(read_level_features=<uint8 CPU tensor, {x.numel() / 1e6:.0f} MB>)) -> CPU tensor"}
+    result["metric_8d"] = {"value": result["host_to_host"]["value"], "unit": "pileup columns/s", "what": "SURVEY.md 8d: host tensor in -> host tensor out"}
     if ranks.rank == 0:
         if args.cpu_budget > 0 and ranks.world == 1:
             # CPU baseline: the functional PyTorch-CPU restatement of LatentSpaceLSTM.forward (oracle/rl_oracle.py, pinned
@@ -449,13 +545,16 @@ def main_rl(args):
                 out = m(torch.from_numpy(np.ascontiguousarray(xs)).to(dev)).cpu().numpy()
             result["cpu_baseline"] = {"value": xs.shape[0] * xs.shape[1] / dt, "unit": "pileup columns/s",
                                       "cores": cores, "kind": "port", "passes": len(times), "median_s": dt,
-                                      "sample": f"{xs.shape[0]} windows x {xs.shape[1]} positions x {D} reads, "
-                                                f"oracle/rl_oracle.py (functional PyTorch-CPU fp32), median of {len(times)} after a warm-up"}
+                                      "sample": f"{xs.shape[0]} windows x {xs.shape[1]} positions x {D} reads (a {B * P // (xs.shape[0] * xs.shape[1])}x smaller "
+                                                f"sample of the {B} x {P} x {D} workload: every window and position costs the same on the CPU path, "
+                                                f"so the rate carries over), oracle/rl_oracle.py (functional PyTorch-CPU fp32), median of {len(times)} after a warm-up"}
             result["parity"] = {"max_abs_dp": float(np.abs(out - ref).max()),
                                 "argmax_identical": bool((out.argmax(-1) == ref.argmax(-1)).all()),
                                 "columns_checked": int(xs.shape[0] * xs.shape[1])}
-        print(json.dumps(result), flush=True)
+        if emit:
+            print(json.dumps(result), flush=True)
     ranks.close()
+    return result if ranks.rank == 0 else None
 
 
 def main():
@@ -533,15 +632,18 @@ def main():
         with torch.inference_mode():
             out_holder["y"] = model.forward(x_dev)
 
-    rec_ms, total_ms, gi_ms, head_ms = [], [], [], []
+    rec_ms, total_ms, gi_ms, head_ms, rec_l0, rec_l1, fused_flags = [], [], [], [], [], [], [0]
 
     def step_timed():
         step()
         t = eng.timing()
         rec_ms.extend(t["rec_ms"])
+        rec_l0.append(t["rec_ms"][0])
+        rec_l1.append(t["rec_ms"][1] if len(t["rec_ms"]) > 1 else 0.0)
         gi_ms.append(sum(t["gi_ms"]))
         head_ms.append(t["head_ms"])
         total_ms.append(t["total_ms"])
+        fused_flags[0] = t["fused_layers"]
 
     log('engine ready, timing')
     if args.device_only:
@@ -562,6 +664,7 @@ def main():
     cols_per_step = B * T
     value = ranks.world * cols_per_step * args.steps / elapsed
     split = eng.split()                     # what the timed steps did: chunks per window, certificate
+    split["ranks_certified"] = int(ranks.sum_over_ranks(1.0 if split["status"] == "certified" else 0.0))     # (every rank splits its own batch)
     split["first_call_audited"] = first_call["audited"]          # (one extra, untimed call before the warm-up steps)
     split["first_call_audit_max_dp"] = first_call["audit_max_dp"]
     sequential = None
@@ -573,6 +676,16 @@ def main():
         sequential = {"value": ranks.world * cols_per_step * 3 / seq_elapsed, "unit": "pileup columns/s",
                       "ms_per_step": 1e3 * seq_elapsed / 3, "steps": 3}
 
+    at_margin_256 = None
+    if split["chunks"] > 1 and not args.device_only and (args.scan_split_margin or 128) < 256:
+        # what a model that needs twice the default margin would run at (the margin is the split scan's price)
+        eng.set_option("scan_split_margin", 256)
+        m_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
+        m_split = eng.split()
+        eng.set_option("scan_split_margin", args.scan_split_margin or 128)
+        step(); torch.cuda.synchronize(dev)                # (back at the default margin; its first call is audited again)
+        at_margin_256 = {"value": ranks.world * cols_per_step * 3 / m_elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * m_elapsed / 3,
+                         "steps": 3, "chunks": m_split["chunks"], "columns": m_split["columns"], "status": m_split["status"]}
     if args.device_only:
         if ranks.rank == 0:
             print(json.dumps({"metric": "pileup columns/sec (consensus bi-GRU inference)", "value": value,
@@ -588,21 +701,28 @@ def main():
     eng.enable_timing(False)
     from medaka_amd.torch_ext import Batch
     x_cpu = torch.from_numpy(x_host)
-    if args.pinned_input:          # what the engine's Batch.collate hands over (page-locked); default: the reference's pageable tensor
-        x_cpu = x_cpu.pin_memory()
-    xb = Batch(counts_matrix=x_cpu)
-    h2h = []
-
-    def host_step():
-        t0 = time.perf_counter()
-        out_holder["p"] = model.predict_on_batch(xb)
-        h2h.append(time.perf_counter() - t0)
-    log('host-to-host batches')
+    # the input tensor as the engine's Batch.collate builds it (page-locked; medaka_amd.torch_ext.stack_counts, installed over
+    # the reference's collate by integration.install) -- and, for comparison, as the reference's torch.stack leaves it (pageable)
+    variants = [("pageable (reference collate)", x_cpu)] if args.pageable_input else \
+               [("page-locked (engine collate)", x_cpu.pin_memory()), ("pageable (reference collate)", x_cpu)]
     if args.stream_host is not None:
         eng.set_option("stream_host", args.stream_host)
-    h_elapsed, _ = dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
-    h2h = h2h[2:]
-    h_med = ranks.max_over_ranks(statistics.median(h2h))
+    h2h_all = {}
+    for vname, xv in variants:
+        xb = Batch(counts_matrix=xv)
+        h2h = []
+
+        def host_step():
+            t0 = time.perf_counter()
+            out_holder["p"] = model.predict_on_batch(xb)
+            h2h.append(time.perf_counter() - t0)
+        log(f'host-to-host batches, input {vname}')
+        dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
+        h2h_all[vname] = (ranks.max_over_ranks(statistics.median(h2h[2:])), len(h2h) - 2)
+        log(f'host-to-host, input {vname}: median {1e3 * h2h_all[vname][0]:.2f} ms')
+    primary = variants[0][0]
+    h_med, n_h2h = h2h_all[primary]
+    xb = Batch(counts_matrix=variants[0][1])
     eng.set_option("stream_host", 0)
     plain = []
     for _ in range(4):
@@ -610,7 +730,6 @@ def main():
         model.predict_on_batch(xb)
         plain.append(time.perf_counter() - t0)
     eng.set_option("stream_host", 1)
-    log(f'host-to-host done: median {1e3 * h_med:.2f} ms streamed, {1e3 * statistics.median(plain):.2f} ms unstreamed')
 
     result = {
         "metric": "pileup columns/sec (consensus bi-GRU inference)",
@@ -637,16 +756,25 @@ def main():
         "sequential_scan": sequential,
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
-            "ms_per_batch_median": 1e3 * h_med, "timed_batches": len(h2h), "warmup": 2,
+            "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2,
             "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
-            "input": "page-locked (engine collate)" if args.pinned_input else "pageable (reference collate)",
-            "what": "model.predict_on_batch(Batch(counts_matrix=<CPU tensor>)) -> CPU tensor, per rank, "
-                    "median over the timed batches, max over ranks; sequential scan: x streams in and probabilities stream "
-                    "out in time slabs under the recurrences; split scan: one copy each way around the device-resident "
-                    "forward (include/medaka_amd.h: mdk_gru_forward)",
-            "unstreamed_ms_per_batch": 1e3 * statistics.median(plain),
+            "input": primary,
+            "other_inputs": {k: {"value": ranks.world * cols_per_step / v[0], "ms_per_batch_median": 1e3 * v[0]}
+                             for k, v in h2h_all.items() if k != primary},
+            "what": "model.predict_on_batch(Batch(counts_matrix=<CPU tensor>)) -> CPU tensor, per rank, the SAME batch object every "
+                    "time (so nothing of it is on the device beforehand), median over the timed batches, max over ranks; a split "
+                    "call copies x in and the result out once each, around the device-resident forward (nothing can run beside "
+                    "recurrences that hold every CU: profiles/r4_experiments/README.md); the fed loop below hands every NEW batch "
+                    "to the device from the Batcher thread, so there the input does not wait for PCIe",
+            "one_copy_each_way_ms_per_batch": 1e3 * statistics.median(plain),
         },
     }
+    result["metric_8d"] = {"value": result["host_to_host"]["value"], "unit": "pileup columns/s",
+                           "ms_per_batch_median": result["host_to_host"]["ms_per_batch_median"],
+                           "what": "SURVEY.md section 8d's metric: columns / wall time of predict_on_batch calls, host tensor in -> host tensor out "
+                                   "(= host_to_host.value; `value` above is the device-resident rate the bench contract asks for)"}
+    if at_margin_256:
+        result["value_at_margin_256"] = at_margin_256
     shared_loop = None
     if args.shared_gpu and ranks.world > 1 and args.loop_batches > 2:
         # K processes per GPU, each running the whole fed loop (loader threads -> engine collate -> predict_on_batch ->
@@ -662,46 +790,49 @@ def main():
     if ranks.rank == 0:
         if shared_loop:
             result["fed_loop_shared"] = shared_loop
-        rec_avg_ms = statistics.mean(rec_ms)
-        rec_flop = REC_FLOP_PER_COLUMN_LAYER * cols_per_step
-        achieved = rec_flop / (rec_avg_ms * 1e-3) / 1e12
-        traffic = None
-        seq_traffic = None
-        try:
-            seq_traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_seq_traffic.json"))).get("k_rec_mfma_bytes_per_launch")
-        except Exception:
-            pass
-        tpath = os.path.join(ROOT, "profiles", "traffic.json" if split["chunks"] > 1 else "r3_seq_traffic.json")
-        if os.path.exists(tpath):
+        n = args.steps
+        tfile = os.path.join(ROOT, "profiles", "traffic.json" if split["chunks"] > 1 else "r3_seq_traffic.json")
+        traffic_doc = None
+        if os.path.exists(tfile) and B == 200 and T == 10000 and not args.half:
             try:
-                traffic = json.load(open(tpath)).get("k_rec_mfma_bytes_per_launch")
+                traffic_doc = json.load(open(tfile))
             except Exception:
-                traffic = None
-        # fp32 parity is bought with an fp16 hi/lo split: 4 fp16 MACs are issued per algorithmic MAC,
-        # so the pipe that bounds this kernel is the fp16 dense MFMA pipe at a quarter of its rate
-        # (half precision mode issues 1 MAC per MAC and is priced against the full rate).
-        issue_factor = 1 if args.half else 4
+                traffic_doc = None
+        kernels, step_level = kernel_table((rec_l0[-n:], rec_l1[-n:], gi_ms[-n:], head_ms[-n:], total_ms[-n:]), fused_flags[0], split, B, T,
+                                           args.half, (traffic_doc or {}).get("families"))
+        # the dominant kernel: the longest per step
+        dom = max(kernels, key=lambda e: e["ms_per_step"])
+        fused1 = bool(fused_flags[0] & 2)
+        if "k_rec_fused" in dom["kernel"]:
+            # MACs the split issues per algorithmic MAC: 3 products in the projection, 4 (the hi|lo row pairs) in the recurrence and head
+            mac_p, mac_r = 196608.0, 98304.0 + (1280.0 if fused_flags[0] & 256 else 0.0)
+            issue_factor = 1.0 if args.half else (3.0 * mac_p + 4.0 * mac_r) / (mac_p + mac_r)
+        else:
+            issue_factor = 1.0 if args.half else 4.0
         peak = PEAK_F16_DENSE_TFLOPS / issue_factor
+        dom_traffic = None
+        if traffic_doc:
+            dom_traffic = traffic_doc.get("k_rec_fused_bytes_per_step") if "k_rec_fused" in dom["kernel"] else traffic_doc.get("k_rec_mfma_bytes_per_launch")
         result["roofline"] = {
-            "kernel": "k_rec_mfma (GRU recurrence; figures are per LAYER PASS = all windows, both directions, every step; "
-                      "layer 0's pass is several resumable launches of the same kernel, whose rocprof durations add up to "
-                      "this span; the algorithmic FLOP are those of the REAL columns -- the margins a split scan adds are overhead)",
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic,
-            "pmc": (pmc_summary(250, rec_avg_ms, traffic) if split["chunks"] > 1 else
-                    pmc_summary(100, rec_avg_ms, seq_traffic, "r3_seq_pmc_step.csv"))
-                   if (B == 200 and T == 10000 and not args.half) else None,
-            "avg_launch_ms": rec_avg_ms, "launches_timed": len(rec_ms),
+            "kernel": dom["kernel"] + " -- one launch = one layer pass over all (virtual) windows, both directions, every step"
+                      + ("" if split["chunks"] == 1 else f"; the split scan runs {split['chunks'] * B} windows of {split['columns']} columns, the "
+                         "algorithmic FLOP are those of the REAL columns (margins are overhead)"),
+            "bound": "mfma", "achieved": dom["algorithmic_tflops"], "peak": peak, "unit": "TFLOP/s",
+            "frac": dom["algorithmic_tflops"] / peak, "traffic": dom_traffic,
+            "frac_issued": dom["frac_issued_of_fp16_peak"],
+            "avg_launch_ms": dom["ms_per_step"], "launches_timed": n,
+            "algorithmic_flop_per_launch": dom["algorithmic_gflop"] * 1e9,
+            "note": f"peak = fp16 dense MFMA {PEAK_F16_DENSE_TFLOPS:.0f} TFLOP/s / {issue_factor:.2f} fp16 MACs issued per algorithmic MAC (fp32 parity through "
+                    "fp16 hi+lo operands: 3 products in the projection, 4 in the recurrence); `frac_issued` counts every MFMA the kernel "
+                    f"executes (row padding, margin columns) against the undivided {PEAK_F16_DENSE_TFLOPS:.0f}; a native fp32-MFMA kernel would be capped at "
+                    f"{PEAK_F32_MATRIX_TFLOPS} TFLOP/s, of which this launch reaches {dom['algorithmic_tflops'] / PEAK_F32_MATRIX_TFLOPS:.2f}",
+            "frac_of_f32_matrix_peak": dom["algorithmic_tflops"] / PEAK_F32_MATRIX_TFLOPS,
+            "kernels": kernels, "step": step_level,
+            "pmc": pmc_summary_r4() if (B == 200 and T == 10000 and not args.half and split["chunks"] > 1 and fused1) else None,
+            "whole_network_tflops": FLOP_PER_COLUMN * cols_per_step / (statistics.mean(total_ms[-n:]) * 1e-3) / 1e12,
             "kernel_launches_per_step": eng.timing()["rec_launches"],
-            "algorithmic_flop_per_launch": rec_flop,
-            "note": f"peak = fp16 dense MFMA {PEAK_F16_DENSE_TFLOPS:.0f} TFLOP/s / {issue_factor} fp16 MACs issued per "
-                    "algorithmic MAC; a native fp32-MFMA kernel would be capped at "
-                    f"{PEAK_F32_MATRIX_TFLOPS} TFLOP/s, of which this launch reaches {achieved / PEAK_F32_MATRIX_TFLOPS:.3f}",
-            "frac_of_f32_matrix_peak": achieved / PEAK_F32_MATRIX_TFLOPS,
-            "whole_network_tflops": FLOP_PER_COLUMN * cols_per_step / (statistics.mean(total_ms) * 1e-3) / 1e12,
-            "kernel_ms_per_step": {"rec": sum(rec_ms) / args.steps, "gi": statistics.mean(gi_ms[-args.steps:]),
-                                   "head": statistics.mean(head_ms[-args.steps:]),
-                                   "device_total": statistics.mean(total_ms[-args.steps:])},
+            "kernel_ms_per_step": {"rec": sum(rec_ms) / args.steps, "gi": statistics.mean(gi_ms[-n:]),
+                                   "head": statistics.mean(head_ms[-n:]), "device_total": statistics.mean(total_ms[-n:])},
         }
         if args.cpu_budget > 0 and ranks.world == 1:   # the CPU baseline is a single-GPU-run figure
             probs = out_holder["p"].numpy()
@@ -722,6 +853,18 @@ def main():
             model.predict_on_counts(cnt, dep, decoded=True)
             diet.append(time.perf_counter() - t0)
         result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[1:])
+    if ranks.world == 1 and not args.shared_gpu and args.extra_rl > 0:
+        # BASELINE config 4b on the same line: the read-level rl_lstm384 architecture, timed by this same run
+        import copy
+        a2 = copy.copy(args)
+        a2.model, a2.steps, a2.warmup, a2.cpu_budget, a2.half = "rl384", 3, 1, (min(args.cpu_budget, args.extra_rl) if args.cpu_budget > 0 else 0), False
+        del model, eng
+        torch.cuda.empty_cache()
+        try:
+            result["extra"] = {"rl384": main_rl(a2, emit=False)}
+        except Exception as exc:                      # the headline line must not depend on it
+            result["extra"] = {"rl384": {"error": f"{type(exc).__name__}: {exc}"}}
+    if ranks.rank == 0:
         print(json.dumps(result), flush=True)
     ranks.close()
 

@@ -29,6 +29,8 @@ def family(name):
         pf, nq, xin, hp = vals[:4]
         twin = " fallback-twin" if pf == "4" else ""
         return f"k_rec_mfma<NQ={nq},XIN={xin},HP={hp}>{twin}"
+    if base == "k_rec_fused" and len(vals) >= 2:
+        return f"k_rec_fused<K={32 * int(vals[0])},HEAD={vals[1]}>"
     return base
 
 
@@ -52,9 +54,13 @@ def main():
     if len(sys.argv) > 3:
         B, T = 200, 10000
         cols = B * T
-        algo = {"k_rec_mfma<NQ=1,XIN=1,HP=0>": cols * (1024 + 512),      # h out 1024 B/col + packed x 1 KB per (4 windows, step, dir)
-                "k_rec_mfma<NQ=1,XIN=0,HP=0>": cols * 4096,              # gi 2 x 1536 + h 1024
-                "k_gi_gemm": cols * (1024 + 3072), "k_head_tiled": cols * (1024 + 20), "k_pack_x": cols * (40 + 512)}
+        vcols = 1000 * 2256          # the split scan's virtual batch at this shape: what the kernels really stream
+        algo = {"k_rec_mfma<NQ=2,XIN=1,HP=0>": vcols * (1024 + 256),     # h out 1024 B/col + packed x 1 KB per (8 windows, step, dir)
+                "k_rec_fused<K=256,HEAD=1>": vcols * (2048 + 1024 + 40),  # both input directions read by both output directions, h out, partial logits
+                "k_rec_fused<K=256,HEAD=0>": vcols * (2048 + 1024),
+                "k_rec_mfma<NQ=2,XIN=0,HP=0>": vcols * 4096,             # (unfused: gi 2 x 1536 + h 1024)
+                "k_gi_gemm": vcols * (1024 + 3072), "k_head_tiled": vcols * 1024 + cols * 20,
+                "k_head_combine": vcols * 40 + cols * 20, "k_pack_x": vcols * (40 + 256), "k_split_gather": (cols + vcols) * 40}
         fams, total = {}, 0.0
         for fam in sorted(acc):
             if "FETCH_SIZE" in acc[fam] or "WRITE_SIZE" in acc[fam]:
@@ -63,13 +69,15 @@ def main():
                              "hbm_bytes_per_step": b, "algorithmic_bytes_per_step": algo.get(fam)}
                 total += b
         # one entry per layer pass (fused layer 0, layer 1), whatever work-group size the step ran with
-        rec = [v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_mfma<") and "twin" not in k]
-        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward at the engine's defaults (split scan: 5 chunks per window, margin 128 -> 1000 virtual windows of 2256 columns; profiles/r3_seq_traffic.json = the sequential scan); rocprofv3 --pmc FETCH_SIZE / "
+        rec = [v["hbm_bytes_per_step"] for k, v in fams.items() if (k.startswith("k_rec_mfma<") or k.startswith("k_rec_fused<")) and "twin" not in k]
+        dom = [v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_fused<")]
+        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward at the engine's defaults (split scan: 5 chunks per window, margin 128 -> 1000 virtual windows of 2256 columns; layer 1's projection and the classifier's Linear fused into its recurrence kernel); rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE in separate passes, summed over every dispatch of the step per kernel family; "
                              "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
                    "families": fams, "total_hbm_bytes_per_step": total,
                    "algorithmic_bytes_per_step": cols * 4156, "ratio_to_algorithmic": total / (cols * 4156),
-                   "k_rec_mfma_bytes_per_launch": (sum(rec) / len(rec)) if rec else None}
+                   "k_rec_mfma_bytes_per_launch": (sum(rec) / len(rec)) if rec else None,
+                   "k_rec_fused_bytes_per_step": dom[0] if dom else None}
         json.dump(traffic, open(sys.argv[3], "w"), indent=1)
         print(json.dumps(traffic, indent=1))
 

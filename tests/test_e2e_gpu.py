@@ -251,3 +251,35 @@ def test_processes_sharing_the_gpu_return_the_same_bits(gold, model, tmp_path):
     assert [p.wait(timeout=300) for p in procs] == [0, 0, 0]
     for k in range(3):
         assert np.array_equal(np.load(tmp_path / f"y{k}.npy"), want), k
+
+
+def test_two_rank_bench_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py on hardware (what the driver's 8-GPU scaling run executes: torch.distributed.run, one
+    rank per device, barrier + MAX over ranks, aggregate value) with both ranks on the one visible GPU (`--shared-gpu`:
+    gloo for the barrier, every engine told it shares the device).  rc 0, one JSON line from rank 0, both ranks' split
+    scans certified, and an aggregate in the band two processes on one MI355X can reach -- not a scaling figure."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MDK_SCAN_SPLIT", None)
+    common = ["--steps", "3", "--warmup", "1", "--cpu-budget", "0", "--loop-batches", "0", "--host-reps", "3", "--extra-rl", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shared-gpu"] + common,
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29677", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                  # rank 0 alone reports
+    r2 = json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "weak" and r2["steps"] == 3
+    assert r2["scan_split"]["ranks_certified"] == 2 and r2["scan_split"]["chunks"] >= 2, r2["scan_split"]
+    ratio = r2["value"] / r1["value"]
+    print(f"two ranks sharing one MI355X: {r2['value'] / 1e6:.1f} M columns/s together against {r1['value'] / 1e6:.1f} M for one "
+          f"({ratio:.2f} x); host-to-host {r2['host_to_host']['value'] / 1e6:.1f} M against {r1['host_to_host']['value'] / 1e6:.1f} M")
+    assert 0.6 <= ratio <= 1.6, ratio
+    assert r2["host_to_host"]["value"] > 0 and r2["roofline"]["kernels"]
