@@ -151,9 +151,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "fuse_l0"              = 1 | 0                  fuse the layer-0 input projection (default 1)
  *   "fuse_proj"            = 1 (auto) | 0 | 2 (always)  layers >= 1: the input projection runs inside the recurrence
  *                                                   kernel, strip by strip, and its result never exists in HBM
- *                                                   (bit-identical to the separate GEMM; fp32-parity mode, 8-window
- *                                                   work-groups, T % 8 == 0; auto: when the call fills the chip, i.e.
- *                                                   whenever "overlap_gemm" would not apply; environment MDK_FUSE_PROJ)
+ *                                                   (bit-identical to the separate GEMM; both precisions, 8-window
+ *                                                   work-groups, T % 8 == 0; auto: when the recurrence's work-groups fill
+ *                                                   the chip (> 208 of them); environment MDK_FUSE_PROJ)
  *   "fuse_head"            = 1 | 0                  with a fused last layer: Linear(D*128 -> 5) inside its kernel as well
  *                                                   (fp16x2-split MFMA on the h image already in LDS; the logits agree with
  *                                                   the fp32 FMA head to ~1e-7, not bit for bit; environment MDK_FUSE_HEAD)

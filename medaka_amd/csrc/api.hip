@@ -342,9 +342,9 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, false>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, true>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
     if (const char *e = getenv("MDK_FUSE_HEAD")) m->opt_fuse_head = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_FUSE_PROJ")) m->opt_fuse_proj = std::min(std::max(atoi(e), 0), 2);
@@ -590,6 +590,9 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // do run side by side, profiles/r3_procs_per_gpu.txt), otherwise the surplus queues behind the others
     const int cu_budget = 232 / m->opt_gpu_share;
     while (nq < (hp ? 4 : 2) && ((n_win + 4 * nq - 1) / (4 * nq)) * D > cu_budget) nq *= 2;
+    // half precision: 8-window work-groups while they fit the chip, so that layers >= 1 can run fused (rec_fused.hpp carries
+    // 8 windows; 16-window groups fill only half the CUs at 1000 chunk-windows)
+    if (hp && nq == 4 && m->opt_fuse_proj && L >= 2 && ((n_win + 7) / 8) * D * m->opt_gpu_share <= 256) nq = 2;
     if (m->opt_tile_windows == 4) nq = 1;
     if (m->opt_tile_windows == 8) nq = 2;
     if (m->opt_tile_windows == 16 && hp) nq = 4;
@@ -657,8 +660,8 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     // GEMM under): the projection runs INSIDE the recurrence kernel, strip by strip, and gi never exists in HBM
     // (rec_fused.hpp; bit-identical to the GEMM + recurrence pair).  fp32-parity mode, 8-window work-groups, T a
     // multiple of the strip.  "fuse_proj" = 2 prefers it to the side-stream GEMM as well.
-    const bool fuse_proj = L >= 2 && !hp && nq == 2 && !ablated && T % kFusedSteps == 0 &&
-                           (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && !overlap_ok));
+    const bool fuse_proj = L >= 2 && nq == 2 && !ablated && T % kFusedSteps == 0 &&
+                           (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && n_wg * D * m->opt_gpu_share > kOvMaxWgs));   // auto: the recurrence fills the chip
     const bool overlap = overlap_ok && !fuse_proj;
     // ... and with it the classifier's Linear (rec_fused.hpp HEAD): the last layer leaves partial logits, k_head_combine
     // finishes them (fp16x2-split MFMA instead of fp32 FMAs: ~1e-7 relative on the logits, not bit for bit)
@@ -752,12 +755,14 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         auto launch = [&](bool xin, const int *cnd, int want) {
             if (fused_proj) {
                 const bool hd = fuse_head && l == L - 1;
-#define MDK_LAUNCH_FUSED(KS, HD)                                                                                              \
-    hipLaunchKernelGGL((k_rec_fused<KS, HD>), rgrid, dim3(512), fused_lds_bytes(KS), s, in, Ld.wih_frag, Ld.bias_gi,          \
+#define MDK_LAUNCH_FUSED(KS, HD, HPF)                                                                                         \
+    hipLaunchKernelGGL((k_rec_fused<KS, HD, HPF>), rgrid, dim3(512), fused_lds_bytes(KS, HPF), s, in, Ld.wih_frag, Ld.bias_gi, \
                        Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi, Ld.up_scale_rec,       \
                        kActScale, reverse_mask, rs0, rns, (const half8 *)m->wlin_frag, m->lin_inv_scale, m->lpart)
-                if (D == 2) { if (hd) MDK_LAUNCH_FUSED(8, true); else MDK_LAUNCH_FUSED(8, false); }
-                else { if (hd) MDK_LAUNCH_FUSED(4, true); else MDK_LAUNCH_FUSED(4, false); }
+#define MDK_LAUNCH_FUSED_P(KS, HD) do { if (hp) MDK_LAUNCH_FUSED(KS, HD, true); else MDK_LAUNCH_FUSED(KS, HD, false); } while (0)
+                if (D == 2) { if (hd) MDK_LAUNCH_FUSED_P(8, true); else MDK_LAUNCH_FUSED_P(8, false); }
+                else { if (hd) MDK_LAUNCH_FUSED_P(4, true); else MDK_LAUNCH_FUSED_P(4, false); }
+#undef MDK_LAUNCH_FUSED_P
 #undef MDK_LAUNCH_FUSED
                 if (hd) m->last.fused_layers |= 1 << 8;
                 m->last.fused_layers |= 1 << l;

@@ -45,9 +45,11 @@ namespace mdk {
 
 constexpr int kFusedSteps = 8;                         // scan steps per strip = rows 2 mt + tt of 4 MFMA row-tiles
 constexpr int kFusedMT = kFusedSteps / 2;
-__host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS) { return (size_t)2 * kFusedMT * KSTEPS * 64 * 16; }
+__host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS, bool hp = false) { return (size_t)(hp ? 1 : 2) * kFusedMT * KSTEPS * 64 * 16; }
 
-template <int KSTEPS, bool HEAD>   // K = 32 * KSTEPS = DIN * 128 input features
+// HP: half-precision mode (`model.half()`): fp16 operands without the hi/lo split -- one product in the projection, one row
+// per window in the recurrence (rows 4g + q of the A image), W_hi only; again bit-identical to the unfused HP pair.
+template <int KSTEPS, bool HEAD, bool HP = false>   // K = 32 * KSTEPS = DIN * 128 input features
 __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const float *__restrict__ act_in,   // act_t of the previous layer (|x| < 1)
     const half8 *__restrict__ wihfrag,  // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]   (as k_gi_gemm)
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const float c_sig = -inv_scale * 1.44269504088896340736f;
     const float c_tanh = 2.0f * inv_scale * 1.44269504088896340736f;
 
-    half8 wf[4][3][2];
+    constexpr int NS = HP ? 1 : 2;          // fp16 pieces per operand
+    half8 wf[4][3][NS];
     {
         const half8 *wp = wfrag + ((size_t)(d * 8 + w8) * 24) * 64 + lane;
 #pragma unroll
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
+                for (int sp = 0; sp < NS; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
     for (int i = tid; i < NIMG * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
 
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
         const int k8 = chunk * 2 + half, ks = k8 >> 2;
         const int slot = (k8 & 3) * 16 + row;
         xs[((0 * MT + mt) * KSTEPS + ks) * 64 + slot] = hi;
-        xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot] = lo;
+        if constexpr (!HP) xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot] = lo;
     };
 
     const int strip0 = s0 / kFusedSteps, strip1 = s_end / kFusedSteps;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
+            for (int sp = 0; sp < NS; ++sp) asm volatile("" ::"v"(wf[ks][gate][sp]));
     asm volatile("" ::"v"(bhn));
     __syncthreads();
     if (s0 > 0) {   // resume: h of scan step s0 - 1 from the output, and its fp16 image (as k_rec_mfma)
@@ -178,8 +181,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             _Float16 hi, lo;
             split_f16(h * kActScale, hi, lo);
             unsigned char *img = hbuf + (s0 & (NIMG - 1)) * kHBufBytes + wr_off;
-            *reinterpret_cast<_Float16 *>(img + (2 * q) * 16) = hi;
-            *reinterpret_cast<_Float16 *>(img + (2 * q + 1) * 16) = lo;
+            if constexpr (HP) {
+                *reinterpret_cast<_Float16 *>(img + q * 16) = hi;
+            } else {
+                *reinterpret_cast<_Float16 *>(img + (2 * q) * 16) = hi;
+                *reinterpret_cast<_Float16 *>(img + (2 * q + 1) * 16) = lo;
+            }
         }
         __syncthreads();
     }
@@ -197,12 +204,17 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
         for (int ks = 0; ks < 4; ++ks) {
             const half8 a = *reinterpret_cast<const half8 *>(img + ks * kHKStride);
             la = mfma16(a, wl[(size_t)(ks * 2 + 0) * 64], la);
-            la = mfma16(a, wl[(size_t)(ks * 2 + 1) * 64], la);
+            if constexpr (!HP) la = mfma16(a, wl[(size_t)(ks * 2 + 1) * 64], la);
         }
         if (c < 5) {
             float *dst = lpart + (((size_t)d * n_tiles + tile) * T + t) * 40 + (2 * g) * 5 + c;
-            dst[0] = (la[0] + la[1]) * lin_inv_scale;      // window 2g:     hi row + lo row
-            dst[5] = (la[2] + la[3]) * lin_inv_scale;      // window 2g + 1
+            if constexpr (HP) {
+                dst[0] = la[0] * lin_inv_scale;                // rows 4g, 4g + 1 = windows 2g, 2g + 1
+                dst[5] = la[1] * lin_inv_scale;
+            } else {
+                dst[0] = (la[0] + la[1]) * lin_inv_scale;      // window 2g:     hi row + lo row
+                dst[5] = (la[2] + la[3]) * lin_inv_scale;      // window 2g + 1
+            }
         }
     };
 
@@ -223,17 +235,20 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     bh[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 0) * 64];
-                    bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
+                    if constexpr (!HP) bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
-                    const half8 al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
+                    half8 al;
+                    if constexpr (!HP) al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                     for (int nt = 0; nt < 3; ++nt) {
                         acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                        if constexpr (!HP) {
+                            acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                            acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
+                        }
                     }
                 }
             }
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
+                for (int sp = 0; sp < NS; ++sp) {
                     ar = mfma16(a[ks], wf[ks][0][sp], ar);
                     az = mfma16(a[ks], wf[ks][1][sp], az);
                 }
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 anh = mfma16(a[ks], wf[ks][2][0], anh);
-                anl = mfma16(a[ks], wf[ks][2][1], anl);
+                if constexpr (!HP) anl = mfma16(a[ks], wf[ks][2][1], anl);
             }
             float rr[2], zz[2], gnv[2];
 #pragma unroll
@@ -289,13 +304,13 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                 const int r = 2 * q + (j & 1);
                 const float gr = acc[j >> 1][0][r], gz = acc[j >> 1][1][r];
                 gnv[q] = acc[j >> 1][2][r];
-                const float tr = gr + (ar[2 * q] + ar[2 * q + 1]);
-                const float tz = gz + (az[2 * q] + az[2 * q + 1]);
+                const float tr = gr + (HP ? ar[q] : (ar[2 * q] + ar[2 * q + 1]));
+                const float tz = gz + (HP ? az[q] : (az[2 * q] + az[2 * q + 1]));
                 rr[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tr * c_sig));
                 zz[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(tz * c_sig));
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4 * NS; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
             }
@@ -303,7 +318,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             float hn[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
+                float tn;
+                if constexpr (HP) tn = anh[q] + bhn;
+                else tn = ((anh[2 * q] + anl[2 * q]) + (anh[2 * q + 1] + anl[2 * q + 1])) + bhn;
                 const float an = __builtin_fmaf(rr[q], tn, gnv[q]);
                 const float e = __builtin_amdgcn_exp2f(an * c_tanh);
                 const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
@@ -315,8 +332,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             for (int q = 0; q < 2; ++q) {
                 _Float16 hi, lo;
                 split_f16(hn[q] * kActScale, hi, lo);
-                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
-                *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                if constexpr (HP) {
+                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + q * 16) = hi;
+                } else {
+                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
+                    *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
+                }
                 op[q] += ostride;
             }
             lds_barrier();

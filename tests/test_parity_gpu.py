@@ -266,8 +266,9 @@ def test_multi_pass_with_overlap_agrees_bitwise(gold):
     e.close()
 
 
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
 @pytest.mark.parametrize("bidirectional", [True, False], ids=["bi", "uni"])
-def test_fused_projection_agrees_bitwise(gold, bidirectional):
+def test_fused_projection_agrees_bitwise(gold, bidirectional, half):
     """Option "fuse_proj" (rec_fused.hpp): layers >= 1 compute their input projection inside the recurrence kernel,
     strip by strip -- the same MFMAs in the same order on the same operands as k_gi_gemm, the same fmaf for scale and
     bias, the same gate arithmetic -- so the probabilities are BIT-IDENTICAL to the GEMM + recurrence pair, whole
@@ -287,6 +288,7 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
         st["linear.bias"] = rng.uniform(-k, k, 5).astype(np.float32)
         kw = dict(bidirectional=False)
     e = engine.GruEngine(st, **kw)
+    e.set_precision(half)
     e.enable_timing(True)
     e.set_option("rec_windows_per_tile", 8)          # the fused kernel carries 8 windows per work-group
     e.set_option("fuse_head", 0)                      # (the fused classifier head is ~1e-7, not bitwise: checked below)
@@ -301,7 +303,7 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
             assert fused == ((2 if T % 8 == 0 else 0) if fp else 0), (B, T, fp, fused)
         n += bool(fused)
         assert np.array_equal(outs[0], outs[2]), (B, T, float(np.abs(outs[0] - outs[2]).max()))
-        if bidirectional:
+        if bidirectional and not half:
             _check(outs[2], oracle.c_gru_forward(x, st) if B * T < 40000 else outs[0], what=f"fused {B}x{T}")
     assert n >= 5
     # the classifier's Linear inside the last layer's kernel (rec_fused.hpp HEAD) + k_head_combine: fp16x2-split MFMA
@@ -315,21 +317,23 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
         fused = e.forward_host(x)
         assert e.timing()["fused_layers"] == (2 | 256), e.timing()
         d = float(np.abs(fused - plain).max())
-        assert d <= 1e-6, (B, T, d)
+        # (half precision: the head sees the fp16 image of h and fp16 W_lin -- what the reference's own autocast Linear
+        # sees -- instead of the fp32 h: rounding of 2^-11 per operand)
+        assert d <= (2e-3 if half else 1e-6), (B, T, d)
         xd = torch.from_numpy(x).cuda()
         yd = torch.empty(B, T, 5, device="cuda")
         e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(yd.cpu().numpy(), fused)            # one launch per layer == resumed launches, bit for bit
         if bidirectional and B * T < 40000:
-            _check(fused, oracle.c_gru_forward(x, st), what=f"fused head {B}x{T}")
+            _check(fused, oracle.c_gru_forward(x, st), tol=2e-3 if half else TOL, what=f"fused head {B}x{T}")
     e.set_option("fuse_head", 0)
     # auto mode: small batches leave CUs idle and keep the GEMM on the side stream; batches that fill the chip fuse
     e.set_option("rec_windows_per_tile", 0)
     e.set_option("fuse_proj", 1)
     e.forward_host(synth.counts_windows(16, 2304, seed=3))
     assert e.timing()["fused_layers"] == 0
-    x = synth.counts_windows(960, 264, seed=4)
+    x = synth.counts_windows(960 if bidirectional else 1920, 264, seed=4)     # > 208 recurrence work-groups of 8 windows
     out = e.forward_host(x)
     assert e.timing()["fused_layers"] == 2
     e.set_option("fuse_proj", 0)
@@ -337,7 +341,7 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional):
     e.set_option("fuse_proj", 1)
     e.set_option("fuse_head", 1)                      # the product default
     out_h = e.forward_host(x)
-    assert e.timing()["fused_layers"] == (2 | 256) and np.abs(out_h - out).max() <= 1e-6
+    assert e.timing()["fused_layers"] == (2 | 256) and np.abs(out_h - out).max() <= (2e-3 if half else 1e-6)
     e.close()
 
 
