@@ -113,9 +113,13 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const long tstep = reverse ? -1 : 1;
     const int s_end = s0 + ns;
     const int t_first = reverse ? (T - 1 - s0) : s0;
-    float *op[2];
+    // (explicitly GLOBAL pointers: through the select of the deferred store's address hipcc otherwise loses the address
+    // space in some instantiations and emits FLAT stores, which count on lgkmcnt as well -- every wait for a staged piece
+    // then becomes vmcnt(0); seen in the ISA of the half-precision build, and in round 3's two-tile experiment)
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat *op[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, q, lane);
+    for (int q = 0; q < 2; ++q) op[q] = (gfloat *)(out + act_block(D, tile, T, t_first) + act_in_block(d, w8, q, lane));
     const long ostride = tstep * (long)(D * 1024);
     float hprev[2] = {0.f, 0.f};
 
@@ -226,7 +230,47 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (HP) {
+            // half precision: 12 MFMAs per k-step (192 cycles) cannot cover an L2 round trip, and there are registers to
+            // spare (no lo halves anywhere): the W_ih fragments of the next THREE k-steps are on their way while one is
+            // multiplied -- four register sets, four k-steps per trip so that the set index is static, requests
+            // unconditional (past the end the last k-step is requested again: a branch would cost vmcnt(0))
+            static_assert(KSTEPS % 4 == 0, "four k-steps per trip");
+            half8 bq[4][3];
+            auto load_b = [&](int ks, int set) {
+                const int k = ks < KSTEPS ? ks : KSTEPS - 1;
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) bq[set][nt] = wp[(size_t)((k * 3 + nt) * 2 + 0) * 64];
+            };
+            auto kstep = [&](int ks, int set) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = mfma16(ah, bq[set][nt], acc[mt][nt]);
+                }
+            };
+            load_b(0, 0); load_b(1, 1); load_b(2, 2);
+#pragma unroll 1
+            for (int ks = 0; ks < KSTEPS; ks += 4) {
+                load_b(ks + 3, 3);
+                __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the requests to where they are consumed)
+                kstep(ks, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(ks + 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ks + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(ks + 5, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ks + 2, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(ks + 6, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ks + 3, 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             // (one register set for the W_ih fragments: the unfused GEMM double-buffers them, here W_hh's 96 registers
             // and the strip's 48 accumulators leave no room -- the SIMD's other wave covers the L2 round trip)
             half8 bh[3], bl[3];
@@ -235,20 +279,17 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) {
                     bh[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 0) * 64];
-                    if constexpr (!HP) bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
+                    bl[nt] = wp[(size_t)((ks * 3 + nt) * 2 + 1) * 64];
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const half8 ah = xs[((0 * MT + mt) * KSTEPS + ks) * 64 + lane];
-                    half8 al;
-                    if constexpr (!HP) al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
+                    const half8 al = xs[((1 * MT + mt) * KSTEPS + ks) * 64 + lane];
 #pragma unroll
                     for (int nt = 0; nt < 3; ++nt) {
                         acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-                        if constexpr (!HP) {
-                            acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
-                            acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
-                        }
+                        acc[mt][nt] = mfma16(al, bh[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16(ah, bl[nt], acc[mt][nt]);
                     }
                 }
             }

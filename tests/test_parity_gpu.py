@@ -345,6 +345,39 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional, half):
     e.close()
 
 
+def test_three_layer_model_with_fused_layers(gold):
+    """`GRUModel(n_layers=3)` (gru.py:13-56 accepts any depth): layers 1 AND 2 run with their projections fused, the last
+    one with the classifier head; bitwise against the unfused pairs, and against the C oracle."""
+    rng = np.random.default_rng(11)
+    k = 1.0 / np.sqrt(128)
+    st = {}
+    for layer, kin in ((0, 10), (1, 256), (2, 256)):
+        for sfx in ("", "_reverse"):
+            st[f"gru.weight_ih_l{layer}{sfx}"] = rng.uniform(-k, k, (384, kin)).astype(np.float32)
+            st[f"gru.weight_hh_l{layer}{sfx}"] = rng.uniform(-k, k, (384, 128)).astype(np.float32)
+            st[f"gru.bias_ih_l{layer}{sfx}"] = rng.uniform(-k, k, 384).astype(np.float32)
+            st[f"gru.bias_hh_l{layer}{sfx}"] = rng.uniform(-k, k, 384).astype(np.float32)
+    st["linear.weight"] = (rng.uniform(-k, k, (5, 256)) * 6).astype(np.float32)
+    st["linear.bias"] = rng.uniform(-k, k, 5).astype(np.float32)
+    e = engine.GruEngine(st, n_layers=3)
+    e.enable_timing(True)
+    e.set_option("rec_windows_per_tile", 8)
+    x = synth.counts_windows(11, 1200, depth=40, seed=5)
+    ref = oracle.c_gru_forward(x, st, n_layers=3)
+    e.set_option("fuse_proj", 0)
+    plain = e.forward_host(x)
+    _check(plain, ref, what="3 layers, unfused")
+    e.set_option("fuse_proj", 2)
+    e.set_option("fuse_head", 0)
+    fused = e.forward_host(x)
+    assert e.timing()["fused_layers"] == 6 and np.array_equal(fused, plain)
+    e.set_option("fuse_head", 1)
+    out = e.forward_host(x)
+    assert e.timing()["fused_layers"] == (6 | 256) and np.abs(out - plain).max() <= 1e-6
+    _check(out, ref, what="3 layers, fused + head")
+    e.close()
+
+
 def test_fused_and_unfused_layer0_agree(gold):
     x = synth.counts_windows(9, 400, seed=41)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"))
