@@ -5,7 +5,7 @@ build:            ## compile the HIP engine (gfx950) and the C oracle in-tree
 	$(PY) -c "import __graft_entry__ as g; g.build()"
 
 test-cpu: build   ## oracle vs reference goldens, host logic, ABI symbols, 2-rank gloo harness
-	$(PY) -m pytest tests -x -q -m "not gpu"
+	$(PY) -m pytest tests -x -q -m "not gpu" --durations=10
 
 test-gpu: build   ## parity tests through the C ABI (needs an MI355X)
 	$(PY) -m pytest tests -x -q -m gpu

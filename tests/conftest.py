@@ -1,6 +1,15 @@
 import os
 import sys
 
+# CPU oracles run PyTorch's OpenMP GRU.  On a box whose cores are busy with something else (other jobs in the container, a
+# second pytest) OpenMP workers that SPIN at every barrier of a 10 000-step loop turn a 30-second suite into tens of
+# minutes (seen by the round-3 review: > 25 min at 600 % CPU; reproduced here next to three training jobs).  Idle
+# workers sleep instead, and the CPU-only suite uses at most four threads -- its cases are small.  (Set before torch
+# is imported; explicit settings in the environment win.)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 import numpy as np
 import pytest
 
@@ -61,7 +70,10 @@ def _built():
     import __graft_entry__ as g
     g.build()
     import torch
-    torch.set_num_threads(usable_cores())      # CPU oracles: never more threads than the cgroup grants
+    n = usable_cores()                         # CPU oracles: never more threads than the cgroup grants ...
+    if not _gpu_available():
+        n = min(n, 4)                          # ... and no more than the small cases of the CPU-only suite can use
+    torch.set_num_threads(n)
 
 
 @pytest.fixture(scope="session")
