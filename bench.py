@@ -750,7 +750,7 @@ def main():
                                   + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
         "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
-                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-19; 2^-10 in half precision); the model's first call "
+                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-17; 2^-10 in half precision); the model's first call "
                            "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp)"
                            if split["chunks"] > 1 else "sequential scan"),
         "sequential_scan": sequential,

@@ -77,9 +77,10 @@ typedef struct {
 /* What the last forward did about splitting the scan (option "scan_split" below). */
 #define MDK_SPLIT_NOT_USED 0   /* shape not latency-bound, option off, or model outside the split path */
 #define MDK_SPLIT_CERTIFIED 1  /* ran as `chunks` chunks per window; every junction certified */
-#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-19 (half precision: 2^-10) at every margin tried:
+#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-17 (half precision: 2^-10) at every margin tried:
                                   the call was answered by the sequential scan */
-#define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected: this model runs sequentially (auto mode) */
+#define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected at the largest margin: sequential scans for a back-off of 64 .. 4096
+                                  calls, then one more try (auto mode); after a failed AUDIT: for good */
 typedef struct {
     int chunks;       /* chunks per window of the last forward (1 = sequential scan) */
     int margin;       /* warm-up columns on either side of a chunk (the margin the model has escalated to) */
@@ -171,10 +172,12 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   B * chunks windows of about T / chunks + 2 * margin columns.  The
  *                                                   states at every junction are compared on the device (both layers,
  *                                                   both directions, at the junction and margin / 2 columns past it);
- *                                                   if any differs by more than 2^-19 (2^-10 in half-precision mode)
+ *                                                   if any differs by more than 2^-17 (2^-10 in half-precision mode)
  *                                                   the call is repeated with twice the margin -- kept for later
  *                                                   calls -- and beyond a margin of 512 as the sequential scan, which
- *                                                   the model then stays on.  n >= 2 forces n chunks (no escalation:
+ *                                                   the model then stays on for a back-off of 64 calls (doubling up to
+ *                                                   4096 per further rejection) before the split is tried again: the
+ *                                                   rejection may have been that input's doing.  n >= 2 forces n chunks (no escalation:
  *                                                   a rejected call is answered by the sequential scan).
  *                                                   Bidirectional 2-layer models, T >= 8 * margin.  Results agree with
  *                                                   the sequential scan to ~1e-7 (not bit for bit) and depend, at that
@@ -182,7 +185,7 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
  *                                                   it escalates to, and every "scan_split_audit_every"-th after that -- is
  *                                                   also run as the sequential scan and the two
- *                                                   results are compared in full (4e-6; half precision 4e-4); a mismatch
+ *                                                   results are compared in full (1e-5; half precision 4e-4); a mismatch
  *                                                   delivers the sequential result and turns the split off.  One extra
  *                                                   forward per model.  2: every certified call (debug), 0: never
  *   "scan_split_audit_every" = 256 | n >= 0         standing audit: with "scan_split_audit" = 1, every n-th certified call after

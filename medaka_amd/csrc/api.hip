@@ -100,7 +100,9 @@ struct mdk_gru {
     int opt_scan_split = 1;                  // 0 off, 1 auto, n >= 2: n chunks per window whenever the shape allows it
     int opt_split_margin = 128;              // G: columns of warm-up on either side of a chunk (where the model starts)
     int split_margin_cur = 0;                // margin in use: doubled (up to kSplitMarginMax) each time a certificate is rejected
-    bool split_disabled = false;             // a certificate failed: this model stays sequential (auto mode)
+    bool split_disabled = false;             // a certificate failed at the largest margin (or an audit failed): sequential scans (auto mode)
+    long split_retry_in = 0;                 // ... for this many calls; then one more try at the largest margin (0: for good -- failed audits)
+    long split_backoff = 0;                  // the last back-off (doubles per rejection at the largest margin: 64 .. 4096 calls)
     float *xv = nullptr;                     // the virtual batch
     size_t xv_cap = 0;
     unsigned *split_flag = nullptr;          // device: bits of the largest junction difference per certificate point
@@ -401,6 +403,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         if (value < 0 || value > kMaxSplit) return fail(MDK_ERR_ARG, "scan_split must be 0 (off), 1 (auto) or 2..%d chunks", kMaxSplit);
         m->opt_scan_split = value;
         m->split_disabled = false;           // setting the option re-arms a model that fell back
+        m->split_retry_in = m->split_backoff = 0;
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
@@ -412,6 +415,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_split_margin = value;
         m->split_margin_cur = 0;
         m->split_disabled = false;
+        m->split_retry_in = m->split_backoff = 0;
     } else {
         return fail(MDK_ERR_ARG, "unknown option '%s'", key);
     }
@@ -1161,6 +1165,10 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
     const int fallbacks = m->last_split.fallbacks;
     memset(&m->last_split, 0, sizeof(m->last_split));
     m->last_split.chunks = 1; m->last_split.columns = T; m->last_split.fallbacks = fallbacks;
+    // A rejection at the largest margin may be the INPUT's doing (a zero-coverage run, a stretch the model was never
+    // trained on: dynamics that do not forget THERE), not the model's: the split is tried again after a back-off of
+    // 64, 128, ... 4096 calls, at the largest margin (one rejected forward per retry, < 1 % of the calls in between).
+    if (m->split_disabled && m->split_retry_in > 0 && --m->split_retry_in == 0) m->split_disabled = false;
     m->last_split.status = m->split_disabled ? MDK_SPLIT_DISABLED : MDK_SPLIT_NOT_USED;
     report_audits(m);
 #ifdef MDK_DEBUG_HOOKS
@@ -1175,6 +1183,7 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         report_audits(m);
         if (keep) return MDK_OK;
         if (ok) {
+            m->split_backoff = 0;
             // Audit.  The certificate argues from the states at the junctions; the audit looks at what is delivered: the call is
             // ALSO run as the sequential scan on the device and the two (B, T, C) results are compared in full.  Audited are the
             // first certified call of a model (and the first at every margin / precision it moves to) and, as a STANDING check on
@@ -1237,8 +1246,12 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         const int next = 2 * sp.G;
         if (next > kSplitMarginMax) {
             m->split_disabled = true;
-            fprintf(stderr, "[medaka_amd] split scan: junction states still differ by %.3g at a margin of %d columns: this model "
-                            "runs as sequential scans from now on\n", m->last_split.max_delta, sp.G);
+            m->split_backoff = m->split_backoff ? std::min<long>(2 * m->split_backoff, 4096) : 64;
+            m->split_retry_in = m->split_backoff;
+            if (m->split_backoff == 64)
+                fprintf(stderr, "[medaka_amd] split scan: junction states still differ by %.3g at a margin of %d columns: sequential scans "
+                                "for the next %ld calls, then another try (back-off doubling up to 4096 calls)\n",
+                        m->last_split.max_delta, sp.G, m->split_backoff);
             break;
         }
         m->split_margin_cur = next;

@@ -26,19 +26,19 @@ from oracle import ref_shim, oracle, zoo_tasks  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-#        name        task           init seed  steps  columns per training window
+#        name        task           seed       steps  columns per training window  [initialisation seed, if not `seed`]
 ZOO = {"maj1":      ("majority",    1,         2500,  300),
        "maj2":      ("majority",    2,         4000,  300),
        "depthmix":  ("depthmix",    3,         2500,  400),
        "hp":        ("homopolymer", 4,         3000,  300),
-       "latch":     ("latch",       8,         2000,  1200),
-       "latch3":    ("latch",       9,         2000,  1200),
+       "latch":     ("latch",       7,         2600,  1600,  6),
        "latch2":    ("latch",       6,         2600,  1000)}
 # curriculum (latch sets): (steps, columns per window, marker distances) -- a latch is learned on short segments first
-# (without it a GRU started on 50-600 column segments never finds the latch in 2000 steps: 64.8 % = the mode ignored; seed 5
-# did not find it WITH the curriculum either -- seeds 6, 8, 9 are the ones kept)
-STAGES = {"latch": [(600, 400, (8, 40)), (600, 600, (20, 150)), (800, 1200, (50, 600))],
-          "latch3": [(600, 400, (8, 40)), (600, 600, (20, 150)), (800, 1200, (50, 600))],
+# (without it a GRU started on 50-600 column segments never finds the latch in 2000 steps: 64.8 % = the mode ignored.  Whether
+# the first stage finds it depends on the initialisation: seeds 5, 8 and 9 sat at 65 % after 1000 steps, seed 6 broke
+# through between steps 500 and 1000.  `latch` therefore starts from seed 6's initialisation too -- optional fifth field --
+# but sees other data and twice the marker distances: a different model with a longer memory.)
+STAGES = {"latch": [(700, 400, (8, 40)), (800, 600, (20, 150)), (1100, 1600, (100, 800))],
           "latch2": [(700, 400, (8, 40)), (800, 600, (20, 150)), (1100, 1000, (50, 400))]}
 
 
@@ -50,8 +50,8 @@ def zoo_input(name, n_windows=2, n_cols=3000):
 
 def train(name, log=print):
     arch, models, te = ref_shim.reference_modules()
-    task, seed, steps, T = ZOO[name]
-    torch.manual_seed(seed)
+    task, seed, steps, T = ZOO[name][:4]
+    torch.manual_seed(ZOO[name][4] if len(ZOO[name]) > 4 else seed)
     model = arch.GRUModel(num_features=10, num_classes=5, gru_size=128)
     model.train()
     model.normalise = False
@@ -111,6 +111,9 @@ def main(argv):
     elif argv[:1] == ["merge"]:
         weights, outs = {}, {}
         for name in ZOO:
+            if not os.path.exists(os.path.join(PARTS, name + ".npz")):
+                print(name, "not trained yet: left out")
+                continue
             d = np.load(os.path.join(PARTS, name + ".npz"))
             weights.update({f"{name}/{k[2:]}": d[k] for k in d.files if k.startswith("w/")})
             outs[name] = d["out"]
@@ -118,7 +121,8 @@ def main(argv):
         np.savez(os.path.join(GOLD, "weights_zoo.npz"), **weights)
         np.savez_compressed(os.path.join(GOLD, "zoo_outputs.npz"), **outs)
         for name in ZOO:
-            print(name, ZOO[name], "held-out accuracy", float(outs[name + "/held_out_accuracy"]))
+            if name in outs:
+                print(name, ZOO[name], "held-out accuracy", float(outs[name + "/held_out_accuracy"]))
     else:
         raise SystemExit(__doc__)
 
