@@ -1,4 +1,4 @@
-"""Weight zoo: further trained weight sets for the consensus GRU, produced by the UNMODIFIED reference's own training
+"""TEST INFRASTRUCTURE (nothing under medaka_amd/ imports this).  Weight zoo: further trained weight sets for the consensus GRU, produced by the UNMODIFIED reference's own training
 step (`TorchModel.process_batch`, medaka/models.py:315-345; RMSprop lr 1e-3 as medaka/training.py:125-133; logits
 during training as medaka/torch_ext.py:300) on the synthetic tasks of oracle/zoo_tasks.py.  Build container only:
 

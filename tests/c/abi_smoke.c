@@ -70,6 +70,17 @@ int main(void) {
         }
         for (int i = 0; i < B * T2 * 5; ++i)
             if (pa[i] != pb[i]) { printf("streamed and plain host paths differ at %d\n", i); return 1; }
+        /* early hand-over: the copy of x2 starts now, the forward redeems the token later; a token is good once */
+        unsigned long long token = 0;
+        for (int i = 0; i < B * T2 * 5; ++i) pb[i] = -1.0f;
+        if (mdk_gru_stage_input(m, x2, B, T2, &token) != MDK_OK || token == 0 ||
+            mdk_gru_forward_staged(m, token, B, T2, pb) != MDK_OK) {
+            printf("staged forward: %s\n", mdk_last_error());
+            return 1;
+        }
+        for (int i = 0; i < B * T2 * 5; ++i)
+            if (pa[i] != pb[i]) { printf("staged and ordinary forwards differ at %d\n", i); return 1; }
+        if (mdk_gru_forward_staged(m, token, B, T2, pb) != MDK_ERR_ARG) { printf("a spent token must be refused\n"); return 1; }
         mdk_host_free(x2); mdk_host_free(pa); mdk_host_free(pb);
     }
     /* argument errors come back as codes + message, never as exit() */
