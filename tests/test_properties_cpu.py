@@ -69,3 +69,29 @@ def test_stack_counts_equals_torch_stack(n, T, step, threads, seed):
     big = rng.random(((n - 1) * step + T, 10), dtype=np.float32)
     feats = [big[i * step:i * step + T] for i in range(n)]
     assert torch.equal(torch_ext.stack_counts(feats, threads=threads), torch.stack([torch.from_numpy(f) for f in feats]).float())
+
+
+def test_bench_kernel_table_arithmetic():
+    """bench.py's roofline bookkeeping (pure arithmetic, no device): MFMA counts per kernel family of the split forward at
+    200 x 10000, algorithmic FLOP on the real columns, fractions of the 2.5 PFLOP/s fp16 peak."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    split = {"chunks": 5, "columns": 2256}
+    k, step = bench.kernel_table(([2.0], [4.0], [0.01], [0.04], [6.2]), 2 | 256, split, 200, 10000, False)
+    by = {e["kernel"].split(" ")[0]: e for e in k}
+    wg_steps = 1000 * 2256 / 8 * 2                       # (8-window work-group, step) pairs of one layer, both directions
+    assert step["windows_per_work_group"] == 8 and step["virtual_columns_scanned"] == 2256000
+    assert abs(by["k_rec_mfma<XIN>"]["issued_gflop"] - wg_steps * 8 * 30 * 16384 / 1e9) < 1e-6
+    assert abs(by["k_rec_fused"]["issued_gflop"] - wg_steps * 8 * (24 + 36 + 1) * 16384 / 1e9) < 1e-6
+    assert abs(by["k_rec_fused"]["algorithmic_gflop"] - 2 * (98304 + 196608 + 1280) * 2e6 / 1e9) < 1e-6
+    assert abs(step["algorithmic_gflop"] - 804352 * 2e6 / 1e9) < 1e-6
+    assert abs(step["frac_issued_of_fp16_peak"] - step["issued_gflop"] / 6.2 / 2500.0) < 1e-12
+    assert 0.4 < step["frac_issued_of_fp16_peak"] < 0.45
+    # the unfused latency regime: 4-window work-groups, GEMM and head as kernels of their own
+    k2, step2 = bench.kernel_table(([6.6], [6.3], [3.6], [0.4], [13.0]), 0, {"chunks": 1, "columns": 10000}, 200, 10000, False)
+    names = [e["kernel"].split(" ")[0] for e in k2]
+    assert names == ["k_rec_mfma<XIN>", "k_rec_mfma", "k_gi_gemm", "k_head_tiled"] and step2["windows_per_work_group"] == 4
