@@ -14,6 +14,11 @@ Reference interface kept (names, argument meaning, error behaviour):
 `forward` is the hand-written HIP engine, not torch.nn.GRU.  There is no CPU path: a model
 whose parameters are not on a HIP device refuses to predict (use the reference class for
 `medaka inference --cpu`).
+
+Interface glue that necessarily reads like the reference's: `TorchModel.device()` and `TorchModel.to_dict()` below follow
+medaka/models.py:291-296 and :347-365 line by line (about twenty lines): `to_dict()` has to produce the very dict
+`model_from_dict` and the model store round-trip, and subclassing the reference classes instead is impossible where
+medaka is not installed (the GPU test box).  Everything else in this file is this repository's own.
 """
 import inspect
 import logging
