@@ -274,8 +274,12 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
     assert touched[0] == total
     timed = n_batches - warm
     cols = timed * batch_size * windows[0].shape[0]
+    # the main thread's own cycle (wait for a batch + predict + hand the rows over): what a long run converges to -- `value`
+    # also pays the writer's last batch after the loop, 1/12 of it here, 1/5000 of a genome's
+    cycle = statistics.median(w + p + h for w, p, h in zip(wait_ms[warm:], predict_ms[warm:], hand_ms[warm:]))
     return {"value": cols / elapsed, "unit": "pileup columns/s", "ms_per_batch": 1e3 * elapsed / timed,
             "timed_batches": timed, "warmup_batches": warm,
+            "main_thread_cycle_ms_median": cycle, "steady_state_value": batch_size * windows[0].shape[0] / (1e-3 * cycle),
             "collate_ms_median": statistics.median(collate_ms[warm:]),
             "predict_ms_median": statistics.median(predict_ms[warm:]),
             "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:]),
@@ -337,6 +341,7 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
     prod = 1 if half else 2                             # MFMAs per (k-step, gate): W_hi and W_lo passes (the hi|lo rows ride along)
     proj_prod = 1 if half else 3
     fused1, fused_head = bool(fused_layers & 2), bool(fused_layers & 256)
+    final_head = bool(fused_layers & 512)               # the scan's second half writes the probabilities itself: no head kernel
     k = []
     def entry(name, ms, algo_mac, mfma, hbm_bytes, note):
         if ms <= 0:
@@ -350,15 +355,17 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
           wg_cols * 8 * (12 * prod + 3 * prod), vcols * (1024 + 1024 / (4 * nq)) + vcols * (40 + 1024 / (4 * nq)),
           "8 waves x (24 + 6) MFMAs per work-group and step")
     if fused1:
-        entry("k_rec_fused (layer 1: K=256 projection + recurrence" + (" + classifier Linear" if fused_head else "") + " in one kernel)", rec1,
+        entry("k_rec_fused (layer 1: K=256 projection + recurrence" + (" + classifier Linear" if fused_head else "") +
+              (" + softmax" if final_head else "") + " in one kernel)", rec1,
               98304 + 196608 + (1280 if fused_head else 0), wg_cols * 8 * (12 * prod + 12 * proj_prod + (1 if fused_head else 0)),
-              vcols * (2048 + 1024 + (40 if fused_head else 0)),
+              vcols * (2048 + 1024 + (40 if fused_head else 0)) + (cols * 20 if final_head else 0),
               "per work-group and strip of 8 steps: 8 waves x (288 projection + 8 x 24 recurrence" + (" + 8 head" if fused_head else "") + ") MFMAs; gi never in HBM")
     else:
         entry("k_rec_mfma (layer 1 recurrence)", rec1, 98304, wg_cols * 8 * 12 * prod, vcols * 4096, "reads gi (3072 B/column), writes h")
         entry("k_gi_gemm (layer 1 projection)", gi, 196608, vcols / 64.0 * 8 * 96 * proj_prod * 2, vcols * 4096, "writes gi as fp32: 3072 B/column")
-    entry("k_head_combine (bias + softmax of the partial logits)" if fused_head else "k_head_tiled (Linear + softmax)", head,
-          0 if fused_head else 1280, 0, (vcols * 40 + cols * 20) if fused_head else (vcols * 1024 + cols * 20), "HBM streaming")
+    if not final_head:
+        entry("k_head_combine (bias + softmax of the partial logits)" if fused_head else "k_head_tiled (Linear + softmax)", head,
+              0 if fused_head else 1280, 0, (vcols * 40 + cols * 20) if fused_head else (vcols * 1024 + cols * 20), "HBM streaming")
     issued_total = sum(e["issued_gflop"] for e in k)
     step = {"device_total_ms": total, "algorithmic_gflop": FLOP_PER_COLUMN * cols / 1e9, "issued_gflop": issued_total,
             "frac_algorithmic_of_fp16_peak": FLOP_PER_COLUMN * cols / total / 1e9 / PEAK_F16_DENSE_TFLOPS if total else None,
@@ -707,7 +714,13 @@ def main():
                [("page-locked (engine collate)", x_cpu.pin_memory()), ("pageable (reference collate)", x_cpu)]
     if args.stream_host is not None:
         eng.set_option("stream_host", args.stream_host)
-    h2h_all = {}
+    # The box's power management is part of this number.  Straight after a stretch of device-resident work the 2-D DMA
+    # copies that carry finished columns home run at a third of their rate for the next ~15 calls (150-200 ms; measured:
+    # profiles/r4_experiments/README.md "host-to-host after a compute burst"), then settle -- a prediction run is in the settled
+    # state from its first second on.  So: the first calls are recorded as they come (`first_calls_ms`), `settle` more
+    # are run untimed, and the median is taken over the timed calls after those.
+    h2h_all, first_calls = {}, {}
+    settle = 24
     for vname, xv in variants:
         xb = Batch(counts_matrix=xv)
         h2h = []
@@ -717,9 +730,11 @@ def main():
             out_holder["p"] = model.predict_on_batch(xb)
             h2h.append(time.perf_counter() - t0)
         log(f'host-to-host batches, input {vname}')
-        dist.timed_steps(ranks, host_step, lambda: None, steps=max(5, args.host_reps), warmup=2)
-        h2h_all[vname] = (ranks.max_over_ranks(statistics.median(h2h[2:])), len(h2h) - 2)
-        log(f'host-to-host, input {vname}: median {1e3 * h2h_all[vname][0]:.2f} ms')
+        n_timed = max(5, args.host_reps)
+        dist.timed_steps(ranks, host_step, lambda: None, steps=n_timed, warmup=2 + settle)
+        h2h_all[vname] = (ranks.max_over_ranks(statistics.median(h2h[-n_timed:])), n_timed)
+        first_calls[vname] = [round(1e3 * t, 3) for t in h2h[:6]]
+        log(f'host-to-host, input {vname}: median {1e3 * h2h_all[vname][0]:.2f} ms (first calls: ' + " ".join(f"{1e3 * t:.1f}" for t in h2h[:6]) + ')')
     primary = variants[0][0]
     h_med, n_h2h = h2h_all[primary]
     xb = Batch(counts_matrix=variants[0][1])
@@ -756,16 +771,19 @@ def main():
         "sequential_scan": sequential,
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
-            "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2,
+            "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2 + settle,
+            "first_calls_ms": first_calls[primary],
             "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
             "input": primary,
             "other_inputs": {k: {"value": ranks.world * cols_per_step / v[0], "ms_per_batch_median": 1e3 * v[0]}
                              for k, v in h2h_all.items() if k != primary},
             "what": "model.predict_on_batch(Batch(counts_matrix=<CPU tensor>)) -> CPU tensor, per rank, the SAME batch object every "
                     "time (so nothing of it is on the device beforehand), median over the timed batches, max over ranks; a split "
-                    "call copies x in and the result out once each, around the device-resident forward (nothing can run beside "
-                    "recurrences that hold every CU: profiles/r4_experiments/README.md); the fed loop below hands every NEW batch "
-                    "to the device from the Batcher thread, so there the input does not wait for PCIe",
+                    "call copies x in once, in front of the forward, and sends the probabilities home in column chunks (2-D DMA copies) "
+                    "under the second half of the last layer's scan, which writes them itself (rec_fused.hpp HEAD = 2); "
+                    "`first_calls_ms`: the calls straight after the device-resident section, while the box's DMA is still in the "
+                    "slow state a compute burst leaves it in (profiles/r4_experiments/README.md); the fed loop below hands every "
+                    "NEW batch to the device from the Batcher thread, so there the input does not wait for PCIe",
             "one_copy_each_way_ms_per_batch": 1e3 * statistics.median(plain),
         },
     }

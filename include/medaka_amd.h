@@ -67,11 +67,12 @@ typedef struct {
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
     int host_streamed;    /* split calls through mdk_gru_forward: bit 1 = the probabilities left in column chunks under the
-                             tail of the last recurrence ("stream_host" = 2; else one copy after the forward); bit 2 = x had
+                             second half of the last layer's scan (option "stream_host"; else one copy after the forward); bit 2 = x had
                              been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call) */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
                              "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both); bit 8: the classifier's Linear
-                             ran inside the last layer's kernel as well ("fuse_head": head_ms is the combine kernel) */
+                             ran inside the last layer's kernel as well ("fuse_head": head_ms is the combine kernel); bit 9: ... and the
+                             scan's second half wrote the probabilities itself ("final_head": no head kernel, head_ms ~ 0) */
 } mdk_gru_timing;
 
 /* What the last forward did about splitting the scan (option "scan_split" below). */
@@ -158,6 +159,12 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *   "fuse_head"            = 1 | 0                  with a fused last layer: Linear(D*128 -> 5) inside its kernel as well
  *                                                   (fp16x2-split MFMA on the h image already in LDS; the logits agree with
  *                                                   the fp32 FMA head to ~1e-7, not bit for bit; environment MDK_FUSE_HEAD)
+ *   "final_head"           = 1 | 0                  with a fused head: the launches of the scan's second half (T % 16 == 0;
+ *                                                   every launch of a one-directional model) add the other direction's
+ *                                                   partial logits, the bias and the softmax themselves and store the
+ *                                                   probabilities -- the arithmetic of the combine kernel, same bits; no
+ *                                                   head kernel, and finished columns can leave for the host while the
+ *                                                   scan runs on (environment MDK_FINAL_HEAD)
  *   "overlap_gemm"         = 1 (auto) | 0 | 2 (force)  project layer 1 (and the head) on a side stream under
  *                                                   the tails of the recurrences (bidirectional, T >= 2048,
  *                                                   T % 16 == 0; auto: while the recurrence leaves CUs idle)
@@ -195,8 +202,11 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   when a model is created, set the defaults of these two options)
  *   "stream_host"          = 1 | 0 | 2              mdk_gru_forward, sequential scan: copy x in / probabilities out in time
  *                                                   slabs under the recurrences (0: one copy before, one after).  A split
- *                                                   call copies once each way (its recurrences hold every CU: nothing can
- *                                                   run beside them); 2 also streams a split call's result (experiments)
+ *                                                   call copies x in once (all of it is needed at once) and sends the
+ *                                                   probabilities home in column chunks under the second half of the last
+ *                                                   layer's scan when that half writes them itself ("final_head"; DMA
+ *                                                   only: no kernel can run beside recurrences that hold every CU);
+ *                                                   2 streams them behind a side-stream head kernel otherwise (experiments)
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
  *                                                   larger batches run as equal passes
  *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid

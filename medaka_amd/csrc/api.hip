@@ -64,6 +64,7 @@ struct mdk_gru {
     int opt_ablate = 0;         // timing-only ablation mask of the recurrence kernel
     size_t max_rows_per_pass = 0;   // 0 = kMaxRowsPerPass
     int opt_fuse_l0 = 1;        // fuse the layer-0 input projection into the recurrence
+    int opt_final_head = 1;     // fused head: the scan's second half writes probabilities itself (rec_fused.hpp HEAD = 2); 0: k_head_combine
     int opt_fuse_head = 1;      // last layer with a fused projection: Linear(D*128 -> 5) inside the recurrence kernel too (rec_fused.hpp HEAD)
     half8 *wlin_frag = nullptr; // [D][4 ksteps][2 hi/lo][64 lanes] B-fragments of linear.weight (classes padded to 16 columns)
     float lin_inv_scale = 1.f;  // 1 / (kActScale * their operand scale)
@@ -344,11 +345,14 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, false, false>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, 0, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, true, false>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, 1, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_fused<8, 2, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(8)));
     if (const char *e = getenv("MDK_FUSE_HEAD")) m->opt_fuse_head = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MDK_FINAL_HEAD")) m->opt_final_head = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_FUSE_PROJ")) m->opt_fuse_proj = std::min(std::max(atoi(e), 0), 2);
 
     *out = m;
@@ -387,6 +391,8 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_fuse_l0 = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_head")) {
         m->opt_fuse_head = value ? 1 : 0;
+    } else if (!strcmp(key, "final_head")) {
+        m->opt_final_head = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_proj")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "fuse_proj must be 0 (off), 1 (auto) or 2 (always)");
         m->opt_fuse_proj = value;
@@ -529,8 +535,10 @@ static int pool_event(mdk_gru *m, hipEvent_t *out) {
 
 // `sp` (split scan): x holds the virtual batch (nb = sp->S * sp->B windows of T = sp->Tv columns) and `probs` is the
 // REAL (sp->B, sp->T, C) result, filled by the head with every chunk's own columns
+// `join_later`: the events behind a split call's last result copies are handed back instead of being waited for on `s`
+// (run_split puts its certificate kernel in front of that wait)
 static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs, hipStream_t s,
-                        EvTimer &tm, const HostIO *io, const SplitPlan *sp = nullptr) {
+                        EvTimer &tm, const HostIO *io, const SplitPlan *sp = nullptr, std::vector<hipEvent_t> *join_later = nullptr) {
     const int D = m->D, L = m->desc.num_layers;
     const long M = (long)nb * T;
     const int reverse_mask = (D == 2) ? 2 : 0;
@@ -672,8 +680,15 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     fuse_head = fuse_proj && m->opt_fuse_head && m->desc.num_classes == 5;
     const bool fuse0 = m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && !ablated;
     const bool stream_in = io_in && can_chunk && fuse0 && m->opt_stream_host;    // x in time slabs under layer 0's (fused) recurrence
-    const bool stream_out = ((io_out && can_chunk) || (sp_out && can_chunk_sp)) && L >= 2 && m->opt_stream_host;   // head chunks copied out under the last recurrence
-    if (sp_out && !stream_out) return fail(MDK_ERR_ARG, "internal: split host streaming asked for a shape that cannot be chunked");
+    // ... and where the scan's second half can deliver the probabilities itself (rec_fused.hpp HEAD = 2: a step's column is
+    // complete once the other direction has passed it): no head kernel, and finished columns can go home by DMA under the
+    // rest of the scan.  Bidirectional: the scan is cut at T/2, a multiple of the strip.  "final_head" = 0: k_head_combine.
+    const bool final_head = fuse_head && m->opt_final_head && (D == 1 || T % (2 * kFusedSteps) == 0);
+    // the result leaves in column chunks under the last recurrence: behind a side-stream head where the recurrence leaves
+    // CUs idle for one (sequential scan of a small batch), behind the launches of a final-head scan (DMA only) -- a split
+    // call otherwise only when forced ("stream_host" = 2: a head kernel beside a recurrence that holds every CU crawls)
+    const bool stream_out = ((io_out && can_chunk) || (sp_out && can_chunk_sp && (final_head || m->opt_stream_host == 2))) &&
+                            L >= 2 && m->opt_stream_host;
     const int F = m->desc.num_features, C = m->desc.num_classes;
     // host -> device copy of the columns [t0, t0 + nt) of every window of this pass
     auto copy_in_cols = [&](int t0, int nt) -> int {
@@ -756,19 +771,24 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     do { if ((A) == 0 && m->opt_deferred_store) MDK_LAUNCH_REC_T(NQV, XIN, HPF, 0, true, CND, WANT); \
          else MDK_LAUNCH_REC_T(NQV, XIN, HPF, A, false, CND, WANT); } while (0)
         // production instantiations
-        auto launch = [&](bool xin, const int *cnd, int want) {
+        // `fin`: this launch's columns are complete (second half of a bidirectional scan, any step of a one-directional
+        // one): the fused head writes probabilities instead of partial logits (rec_fused.hpp HEAD = 2)
+        auto launch = [&](bool xin, const int *cnd, int want, bool fin = false) {
             if (fused_proj) {
-                const bool hd = fuse_head && l == L - 1;
+                const int hd = (fuse_head && l == L - 1) ? (fin ? 2 : 1) : 0;
 #define MDK_LAUNCH_FUSED(KS, HD, HPF)                                                                                         \
     hipLaunchKernelGGL((k_rec_fused<KS, HD, HPF>), rgrid, dim3(512), fused_lds_bytes(KS, HPF), s, in, Ld.wih_frag, Ld.bias_gi, \
                        Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi, Ld.up_scale_rec,       \
-                       kActScale, reverse_mask, rs0, rns, (const half8 *)m->wlin_frag, m->lin_inv_scale, m->lpart)
+                       kActScale, reverse_mask, rs0, rns, (const half8 *)m->wlin_frag, m->lin_inv_scale, m->lpart,          \
+                       (const float *)m->lin_b, probs, nb, (int)m->desc.normalise, sp ? *sp : SplitPlan{})
 #define MDK_LAUNCH_FUSED_P(KS, HD) do { if (hp) MDK_LAUNCH_FUSED(KS, HD, true); else MDK_LAUNCH_FUSED(KS, HD, false); } while (0)
-                if (D == 2) { if (hd) MDK_LAUNCH_FUSED_P(8, true); else MDK_LAUNCH_FUSED_P(8, false); }
-                else { if (hd) MDK_LAUNCH_FUSED_P(4, true); else MDK_LAUNCH_FUSED_P(4, false); }
+#define MDK_LAUNCH_FUSED_H(KS) do { if (hd == 2) MDK_LAUNCH_FUSED_P(KS, 2); else if (hd == 1) MDK_LAUNCH_FUSED_P(KS, 1); else MDK_LAUNCH_FUSED_P(KS, 0); } while (0)
+                if (D == 2) MDK_LAUNCH_FUSED_H(8); else MDK_LAUNCH_FUSED_H(4);
+#undef MDK_LAUNCH_FUSED_H
 #undef MDK_LAUNCH_FUSED_P
 #undef MDK_LAUNCH_FUSED
                 if (hd) m->last.fused_layers |= 1 << 8;
+                if (hd == 2) m->last.fused_layers |= 1 << 9;
                 m->last.fused_layers |= 1 << l;
                 return;
             }
@@ -806,6 +826,44 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
                 default: return fail(MDK_ERR_ARG, "unsupported ablation mask %d", abl);
             }
 #undef MDK_ABL_CASE
+        } else if (final_head && l == L - 1) {
+            // last layer, fused head: [0, T/2) leaves partial logits, the launches after T/2 (every launch of a
+            // one-directional scan) deliver probabilities; on the host path the second half is cut again so that what it has
+            // finished -- columns [T - s', T - s) + [s, s') after the launch [s, s') -- crosses PCIe under the next launch
+            std::vector<int> ph{0};
+            if (D == 2) {
+                ph.push_back(T / 2);
+                // (a launch's columns must have crossed PCIe before the next launch ends: ~0.9 us per column pair of a
+                // 200-window batch + ~10 us per copy against 1.8 us per step -- halvings keep that.  A split scan's LAST launch
+                // is its outer margin, [T - G, T): only the two edge chunks deliver anything from it -- the first and last G
+                // columns of every window, two copies -- so all but those have left when the scan ends.
+                // MDK_OUT_HALVINGS: experiments)
+                static const int env_cuts = getenv("MDK_OUT_HALVINGS") ? atoi(getenv("MDK_OUT_HALVINGS")) : 0;
+                if (stream_out) {
+                    const int last_cut = sp ? T - sp->G : T;
+                    for (int k = 1; k <= (env_cuts > 0 ? env_cuts : (sp ? 3 : 4)); ++k) {
+                        const int cut = T / 2 + ((T / 2) - ((T / 2) >> k)) / kFusedSteps * kFusedSteps;
+                        if (cut > ph.back() && cut < T && (!sp || cut + 64 < last_cut)) ph.push_back(cut);
+                    }
+                    if (sp && last_cut > ph.back() && last_cut % kFusedSteps == 0) ph.push_back(last_cut);
+                }
+            }
+            ph.push_back(T);
+            for (size_t p = 0; p + 1 < ph.size(); ++p) {
+                rs0 = ph[p]; rns = ph[p + 1] - ph[p];
+                const bool fin = D == 1 || p >= 1;
+                launch(false, nullptr, 0, fin);
+                m->last.rec_launches++;
+                if (!(stream_out && fin && D == 2)) continue;
+                hipEvent_t ev;
+                if ((rc = pool_event(m, &ev))) return rc;
+                HIP_TRY(hipEventRecord(ev, s));
+                const int lo0 = T - ph[p + 1], hi0 = ph[p], len = ph[p + 1] - ph[p];
+                if (lo0 + len == hi0) out_ranges.push_back({ev, lo0, 2 * len});
+                else { out_ranges.push_back({ev, lo0, len}); out_ranges.push_back({ev, hi0, len}); }
+            }
+            m->last.rec_launches--;   // (+1 below)
+            head_done = true;
         } else if (slabs || side_gemm || side_head) {
             // The scan is cut into phases [ph[p], ph[p+1]).  First half: one phase, or -- when x is still
             // arriving -- four that double in length, each behind the copy of its two slabs.  Second half:
@@ -921,7 +979,10 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     if (!head_done) launch_head(in, s, 0, T);
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
-    if (sp_out) {
+    if (sp_out && !stream_out) {
+        HIP_TRY(hipMemcpyAsync(io->p_host, probs, (size_t)sp->B * sp->T * C * sizeof(float), hipMemcpyDeviceToHost, s));
+    } else if (sp_out) {
+        m->last.host_streamed |= 2;
         // split host path: each head chunk delivered, for chunk k, the real columns core_k /\ (start[k] + [t0, t0 + nt)): they
         // leave for the caller's buffer behind the chunk's event as 2-D DMA copies (B rows of a few KB: 37-50 GB/s,
         // profiles/r4_experiments/dma2d_probe.txt) -- DMA, not a copy kernel: any kernel that talks to host memory from
@@ -945,7 +1006,8 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
             hipEvent_t done;
             if ((rc = pool_event(m, &done))) return rc;
             HIP_TRY(hipEventRecord(done, cs));
-            HIP_TRY(hipStreamWaitEvent(s, done, 0));
+            if (join_later) join_later->push_back(done);
+            else HIP_TRY(hipStreamWaitEvent(s, done, 0));
         }
     } else if (io_out) {
         if (out_ranges.empty()) {      // head not chunked, or its chunks were not streamed: one copy behind it
@@ -1074,7 +1136,7 @@ static bool split_stream_ok(const mdk_gru *m, int Tv) {
 
 static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
                      const float *x_host, float *probs_host, bool *certified) {
-    const size_t F = m->desc.num_features, C = m->desc.num_classes;
+    const size_t F = m->desc.num_features;
     const int Bv = sp.S * sp.B;
     const size_t cols = (size_t)Bv * sp.Tv;
     memset(&m->last, 0, sizeof(m->last));
@@ -1089,20 +1151,15 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     int rc = ensure_workspace(m, (((size_t)Bv + kTileWin - 1) / kTileWin * kTileWin) * (size_t)sp.Tv);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(m->split_flag, 0, kSplitFlagWords * sizeof(unsigned), s));
-    // The host buffers cross PCIe whole, as one copy each way, around the device-resident split forward: the time-slab
-    // streaming of the sequential host path would have to copy S strided pieces per slab, and strided copies with
-    // short rows run at half the rate of a contiguous one (profiles/r3_experiments/scan_split/host_path.txt)
     // Host buffers.  x crosses PCIe whole, one contiguous copy in front of the forward: all of it is needed within the
     // first half of layer 0 (1 ms of work against 1.4 ms of PCIe), so slabs gain nothing -- measured both as DMA slabs and
     // as copy kernels on the mapped buffer (profiles/r4_experiments/README.md); callers that can, hand x over early
     // (medaka_amd.torch_ext: the batch is on its way to the device while the previous one is still being computed).
-    // The probabilities leave chunk by chunk behind the classifier head, as 2-D DMA copies under the tail of the last
-    // recurrence (forward_pass); what stays exposed is the last chunk.
-    // ... and gains nothing while a separate classifier-head kernel has to run beside a recurrence that holds every CU: the
-    // head chunks crawl until the recurrence is over and everything serialises at the end (9.4 ms against 9.1,
-    // profiles/r4_experiments/host_path_timeline_v4_dma_out.txt).  "stream_host" = 2 forces it (experiments); by default a
-    // split call copies its result out once, behind the head.
-    const bool stream_out = probs_host && m->opt_stream_host == 2 && split_stream_ok(m, sp.Tv);
+    // The probabilities leave in column chunks, as 2-D DMA copies under the rest of the last layer's scan, whose second
+    // half writes them itself (rec_fused.hpp HEAD = 2; forward_pass decides: `host_streamed` bit 1) -- behind a separate
+    // head kernel they did not (a kernel beside a recurrence that holds every CU crawls until the recurrence is over: 9.4 ms
+    // against 9.1, profiles/r4_experiments/host_path_timeline_v4_dma_out.txt; "stream_host" = 2 still forces that form).
+    // What stays exposed is the last launch's chunk; a shape that cannot be chunked leaves as one copy behind the forward.
     if (x_host)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
     {
@@ -1113,17 +1170,16 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
                            x_dev, m->xv, sp, (int)F, vec, 0, sp.Tv);
     }
     HostIO io;
-    io.p_host = stream_out ? probs_host : nullptr;
-    m->last.host_streamed = stream_out ? 2 : 0;
+    io.p_host = probs_host;
     EvTimer tm{m, s};
-    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, stream_out ? &io : nullptr, &sp);
+    std::vector<hipEvent_t> out_done;      // (the last result chunks are still crossing PCIe while the certificate is computed)
+    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, probs_host ? &io : nullptr, &sp, &out_done);
     if (rc) return rc;
     hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
                        (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);
     HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    for (hipEvent_t e : out_done) HIP_TRY(hipStreamWaitEvent(s, e, 0));
     HIP_TRY(hipGetLastError());
-    if (probs_host && !stream_out)
-        HIP_TRY(hipMemcpyAsync(probs_host, probs_dev, (size_t)sp.B * sp.T * C * sizeof(float), hipMemcpyDeviceToHost, s));
     if ((rc = finish_timing(m, tm, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
     const float eps = m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps;

@@ -49,7 +49,13 @@ __host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS, bool hp 
 
 // HP: half-precision mode (`model.half()`): fp16 operands without the hi/lo split -- one product in the projection, one row
 // per window in the recurrence (rows 4g + q of the A image), W_hi only; again bit-identical to the unfused HP pair.
-template <int KSTEPS, bool HEAD, bool HP = false>   // K = 32 * KSTEPS = DIN * 128 input features
+//
+// HEAD = 2 (the launches of the second half of a bidirectional scan, or every launch of a one-directional one): the column a
+// step finishes is COMPLETE -- the other direction left its partial logits there in an earlier launch -- so the wave adds
+// them, the bias, takes the softmax (the arithmetic of k_head_combine, operation for operation: same bits) and stores the
+// 5 probabilities where the caller wants them ((B, T, 5); a split scan's chunk: its own columns of the real window).  No
+// head kernel at all then, and -- the point -- finished columns can leave for the host by DMA while the scan runs on.
+template <int KSTEPS, int HEAD, bool HP = false>   // K = 32 * KSTEPS = DIN * 128 input features
 __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const float *__restrict__ act_in,   // act_t of the previous layer (|x| < 1)
     const half8 *__restrict__ wihfrag,  // [D][8 waves][KSTEPS][3 gates][2 hi/lo][64 lanes]   (as k_gi_gemm)
@@ -63,8 +69,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     int reverse_mask, int s0, int ns,
     const half8 *__restrict__ wlin_frag,   // HEAD: W_lin B-fragments [D][4 ksteps][2 hi/lo][64 lanes] (column n = class, n >= 5 zero)
     float lin_inv_scale,                   // HEAD: 1 / (kActScale * W_lin's operand scale)
-    float *__restrict__ lpart)             // HEAD: partial logits [D][n_tiles][T][8 windows][5]
+    float *__restrict__ lpart,             // HEAD: partial logits [D][n_tiles][T][8 windows][5]
+    const float *__restrict__ lin_b,       // HEAD = 2: classifier bias [5]
+    float *__restrict__ probs,             // HEAD = 2: the result, (nb, T, 5) or the split plan's (B, T, 5)
+    int nb, int normalise, SplitPlan spl)  // HEAD = 2: windows of this pass; softmax or raw logits; spl.S > 1: split scan
 {
+    constexpr bool FIN = HEAD == 2;
     constexpr int DIN = KSTEPS / 4;
     constexpr int NP = DIN * 128;               // 8-float pieces per activation block
     constexpr int MT = kFusedMT;
@@ -74,6 +84,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     half8 *xs = reinterpret_cast<half8 *>(smem);            // [split 2][mt MT][KSTEPS][64 lanes]
     constexpr int NIMG = HEAD ? 8 : 2;      // images of h kept: the step's two, or a whole strip's for the head
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[NIMG * kHBufBytes];
+    struct FinRow { long base; int lo, hi; };        // HEAD = 2: window w of the tile delivers local columns [lo, hi) to probs + base + 5 t
+    __shared__ FinRow ftab[FIN ? kTileWin : 1];
     __builtin_amdgcn_s_setprio(MDK_REC_PRIO);
 
     const int tid = threadIdx.x;
@@ -100,6 +112,24 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                 for (int sp = 0; sp < NS; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
     for (int i = tid; i < NIMG * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+    if constexpr (FIN) {
+        if (tid < kTileWin) {
+            const int win = tile * kTileWin + tid;
+            FinRow r{0, 0, 0};
+            if (win < nb) {
+                if (spl.S > 1) {
+                    const int k = win / spl.B;
+                    r.lo = spl.core0[k] - spl.start[k];
+                    r.hi = spl.core0[k + 1] - spl.start[k];
+                    r.base = ((long)(win - k * spl.B) * spl.T + spl.start[k]) * 5;
+                } else {
+                    r.hi = T;
+                    r.base = (long)win * T * 5;
+                }
+            }
+            ftab[tid] = r;
+        }
+    }
 
     const int u = 16 * w8 + c;
     const float bhn = b_hn[d * kH + u] * (1.0f / inv_scale);
@@ -198,6 +228,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const half8 *wp = wihfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
 
     // HEAD: partial logits of strip `hs`, one scan step per wave (the image of h after step s sits in slot (s + 1) % 8)
+    typedef const __attribute__((address_space(1))) float cgfloat;
+    const int cc = c < 5 ? c : 4;
+    // HEAD = 2: the other direction's partial logits of this wave's column, requested under step 6 of the strip (nothing
+    // else is in flight then) and used at the top of the next one
+    cgfloat *lp_other = (cgfloat *)(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40 + (2 * g) * 5 + cc);
+    float oth[2] = {0.f, 0.f}, lb = 0.f;
     auto head_strip = [&](int hs) {
         const int s = hs * kFusedSteps + w8;
         const int t = reverse ? (T - 1 - s) : s;
@@ -210,14 +246,54 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             la = mfma16(a, wl[(size_t)(ks * 2 + 0) * 64], la);
             if constexpr (!HP) la = mfma16(a, wl[(size_t)(ks * 2 + 1) * 64], la);
         }
-        if (c < 5) {
-            float *dst = lpart + (((size_t)d * n_tiles + tile) * T + t) * 40 + (2 * g) * 5 + c;
-            if constexpr (HP) {
-                dst[0] = la[0] * lin_inv_scale;                // rows 4g, 4g + 1 = windows 2g, 2g + 1
-                dst[5] = la[1] * lin_inv_scale;
-            } else {
-                dst[0] = (la[0] + la[1]) * lin_inv_scale;      // window 2g:     hi row + lo row
-                dst[5] = (la[2] + la[3]) * lin_inv_scale;      // window 2g + 1
+        float own[2];
+        if constexpr (HP) {
+            own[0] = la[0] * lin_inv_scale;                // rows 4g, 4g + 1 = windows 2g, 2g + 1
+            own[1] = la[1] * lin_inv_scale;
+        } else {
+            own[0] = (la[0] + la[1]) * lin_inv_scale;      // window 2g:     hi row + lo row
+            own[1] = (la[2] + la[3]) * lin_inv_scale;      // window 2g + 1
+        }
+        if constexpr (!FIN) {
+            if (c < 5) {
+                float *dst = lpart + (((size_t)d * n_tiles + tile) * T + t) * 40 + (2 * g) * 5 + c;
+                dst[0] = own[0];
+                dst[5] = own[1];
+            }
+        } else {
+            // k_head_combine's arithmetic (head.hpp), operation for operation: (part_0 + part_1) + bias; largest; exp; the
+            // five terms summed in class order; quotient.  The 5 logits of a window sit in lanes 16 g + 0..4.
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v = own[q];
+                if constexpr (DIN == 2) v = d == 0 ? own[q] + oth[q] : oth[q] + own[q];
+                v += lb;
+                float res = v;
+                if (normalise) {
+                    float a[5];
+#pragma unroll
+                    for (int cl = 0; cl < 5; ++cl) a[cl] = __shfl(v, (lane & 48) + cl);
+                    float mx = a[0];
+#pragma unroll
+                    for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, a[cl]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int cl = 0; cl < 5; ++cl) sum += __expf(a[cl] - mx);
+                    res = __expf(v - mx) / sum;
+                }
+                const FinRow r = ftab[2 * g + q];
+                if (c < 5 && t >= r.lo && t < r.hi) probs[r.base + (long)t * 5 + c] = res;
+            }
+        }
+    };
+    auto head_request = [&](int hs) {
+        if constexpr (FIN) {
+            lb = ((cgfloat *)lin_b)[cc];
+            if constexpr (DIN == 2) {
+                const int s = hs * kFusedSteps + w8;
+                const int t = reverse ? (T - 1 - s) : s;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) oth[q] = lp_other[(size_t)t * 40 + q * 5];
             }
         }
     };
@@ -326,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                 }
             }
             if (j % kIssue == 0 && j / kIssue < NPIECE) pc[j / kIssue] = piece_load(nstrip, j / kIssue);
+            if (j == 6) head_request(strip);
             // deferred store of the previous step's h (rec_mfma.hpp DS), unconditional: the first step of a launch writes its
             // incoming state (zero, or the resumed h) into its OWN slot, which the next step's store then overwrites
             const long back = step > s0 ? ostride : 0;

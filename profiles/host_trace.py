@@ -20,7 +20,7 @@ e = engine.GruEngine(w)
 e.set_option("scan_split_audit", 0)
 px, pp = engine.PinnedArray(x.shape), engine.PinnedArray((B, T, 5))
 px.array[...] = x
-for label, opts in (("result streamed behind the head", {"stream_host": 2}), ("one copy each way", {"stream_host": 1})):
+for label, opts in (("result in column chunks under the scan's second half", {"stream_host": 1}), ("one copy each way", {"stream_host": 0})):
     for k, v in opts.items():
         e.set_option(k, v)
     for i in range(5):

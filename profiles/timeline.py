@@ -1,6 +1,7 @@
 """Kernel / copy timeline of the LAST call of each configuration in a rocprofv3 trace of profiles/host_trace.py.
-   python profiles/timeline.py RESULTS.db [OUT.txt]
-A call ends with its k_split_verify dispatch; everything between two of those is one call."""
+   python profiles/timeline.py RESULTS.db [OUT.txt] [CALLS]
+A call ends with its k_split_verify dispatch; everything between two of those is one call.  CALLS: comma-separated call
+indices to print instead (negative: from the end), e.g. "-6,-2" for a trace of bench.py."""
 import re
 import sqlite3
 import sys
@@ -32,7 +33,10 @@ def main():
     ends = [i for i, e in enumerate(ev) if e[2] == "K" and e[3].startswith("k_split_verify")]
     lines = []
     # the last call of the first half of the verify dispatches (configuration 1) and the very last call (configuration 2)
-    for label, idx in (("configuration 1, last call", len(ends) // 2 - 1), ("configuration 2, last call", len(ends) - 1)):
+    picks = (("configuration 1, last call", len(ends) // 2 - 1), ("configuration 2, last call", len(ends) - 1))
+    if len(sys.argv) > 3:
+        picks = tuple((f"call {int(c)} of {len(ends)}", int(c) % len(ends)) for c in sys.argv[3].split(","))
+    for label, idx in picks:
         if idx < 1:
             continue
         lo, hi = ends[idx - 1] + 1, ends[idx]

@@ -309,13 +309,17 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional, half):
     # the classifier's Linear inside the last layer's kernel (rec_fused.hpp HEAD) + k_head_combine: fp16x2-split MFMA
     # instead of fp32 FMAs, so ~1e-7 on the probabilities instead of identical bits; whole and resumed layers
     e.set_option("fuse_proj", 2)
-    for B, T in ((13, 2304), (9, 8), (3, 1000), (17, 4096)):
+    for B, T in ((13, 2304), (9, 8), (5, 16), (21, 272), (3, 1000), (17, 4096)):
         x = synth.counts_windows(B, T, depth=40, seed=B * 1000 + T)
         e.set_option("fuse_head", 0)
         plain = e.forward_host(x)
         e.set_option("fuse_head", 1)
         fused = e.forward_host(x)
-        assert e.timing()["fused_layers"] == (2 | 256), e.timing()
+        # (bit 9: the scan's second half wrote the probabilities itself -- one-directional: every launch)
+        assert e.timing()["fused_layers"] == (2 | 256 | (512 if (T % 16 == 0 or not bidirectional) else 0)), e.timing()
+        e.set_option("final_head", 0)                              # ... against k_head_combine: the same bits
+        assert np.array_equal(e.forward_host(x), fused) and e.timing()["fused_layers"] == (2 | 256)
+        e.set_option("final_head", 1)
         d = float(np.abs(fused - plain).max())
         # (half precision: the head sees the fp16 image of h and fp16 W_lin -- what the reference's own autocast Linear
         # sees -- instead of the fp32 h: rounding of 2^-11 per operand)
@@ -341,7 +345,7 @@ def test_fused_projection_agrees_bitwise(gold, bidirectional, half):
     e.set_option("fuse_proj", 1)
     e.set_option("fuse_head", 1)                      # the product default
     out_h = e.forward_host(x)
-    assert e.timing()["fused_layers"] == (2 | 256) and np.abs(out_h - out).max() <= (2e-3 if half else 1e-6)
+    assert e.timing()["fused_layers"] & 0x1ff == (2 | 256) and np.abs(out_h - out).max() <= (2e-3 if half else 1e-6)
     e.close()
 
 
@@ -373,8 +377,10 @@ def test_three_layer_model_with_fused_layers(gold):
     assert e.timing()["fused_layers"] == 6 and np.array_equal(fused, plain)
     e.set_option("fuse_head", 1)
     out = e.forward_host(x)
-    assert e.timing()["fused_layers"] == (6 | 256) and np.abs(out - plain).max() <= 1e-6
+    assert e.timing()["fused_layers"] == (6 | 256 | 512) and np.abs(out - plain).max() <= 1e-6
     _check(out, ref, what="3 layers, fused + head")
+    e.set_option("final_head", 0)
+    assert np.array_equal(e.forward_host(x), out) and e.timing()["fused_layers"] == (6 | 256)
     e.close()
 
 

@@ -297,11 +297,12 @@ def test_counts_in_decoded_out_at_full_size_through_the_split_scan(gold):
 
 @pytest.mark.parametrize("B,T", [(200, 10000), (100, 10000), (10, 10000), (37, 9999), (3, 3073), (1, 10000)])
 def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
-    """`mdk_gru_forward` of a split call.  With option "stream_host" = 2 the probabilities leave in column chunks (2-D DMA
-    copies) behind the classifier head, under the tail of the last recurrence (api.hip run_split / forward_pass HostIO),
-    page-locked or pageable buffers alike -- measured a small loss, so not the default, but it must stay correct: only
-    data movement and the cut of the last scan into resumed launches differ, the bits must be those of the device entry
-    and of the default path (one copy each way).  A batch handed over early (`mdk_gru_stage_input`) gives the same bits."""
+    """`mdk_gru_forward` of a split call.  The probabilities leave in column chunks (2-D DMA copies) under the second half of
+    the last layer's scan (api.hip run_split / forward_pass HostIO), page-locked or pageable buffers alike: by default
+    when that half writes them itself (rec_fused.hpp HEAD = 2, `fused_layers` bit 9), with option "stream_host" = 2 also
+    behind a side-stream head kernel (measured a small loss, but it must stay correct), with 0 never.  Only data movement
+    and the cut of the last scan into resumed launches differ: the bits must be those of the device entry in every form.
+    A batch handed over early (`mdk_gru_stage_input`) gives the same bits."""
     x = synth.counts_windows(B, T, depth=40, seed=11 * B + T)
     e = engine.GruEngine(gold["weights_trained"])
     e.enable_timing(True)
@@ -313,20 +314,33 @@ def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
     assert info["status"] == "certified", info
     want = yd.cpu().numpy()
     streamable = e.split()["columns"] >= 512
-    plain = e.forward_host(x)                                  # pageable in, pageable out; default: one copy each way
-    assert e.timing()["host_streamed"] == 0 and np.array_equal(plain, want)
+    plain = e.forward_host(x)                                  # pageable in, pageable out
+    t = e.timing()
+    assert np.array_equal(plain, want)
+    assert bool(t["host_streamed"] & 2) == (streamable and bool(t["fused_layers"] & 512)), (t, e.split())
+    if B * T >= 1000000:
+        assert t["host_streamed"] & 2, t                       # the product shapes do take the streamed form
+    e.set_option("final_head", 0)                              # the combine kernel instead: one copy behind it, same bits
+    assert np.array_equal(e.forward_host(x), want) and e.timing()["host_streamed"] == 0 and not e.timing()["fused_layers"] & 512
     pin_x, pin_p = engine.PinnedArray(x.shape), engine.PinnedArray(want.shape)
     pin_x.array[...] = x
-    e.set_option("stream_host", 2)                             # the result leaves chunk by chunk behind the head
+    e.set_option("stream_host", 2)                             # ... and its chunks behind a side-stream head kernel
+    for rep in range(2):
+        pin_p.array[...] = -1.0
+        out = e.forward_host(pin_x.array, out=pin_p.array)
+        assert e.timing()["host_streamed"] == (2 if streamable else 0), (e.timing(), e.split())
+        assert np.array_equal(out, want), (rep, float(np.abs(out - want).max()))
+    e.set_option("final_head", 1)
     for rep in range(3):                                       # repeated: the chunks land in a recycled buffer
         pin_p.array[...] = -1.0
         out = e.forward_host(pin_x.array, out=pin_p.array)
         assert e.timing()["host_streamed"] == (2 if streamable else 0), (e.timing(), e.split())
         assert np.array_equal(out, want), (rep, float(np.abs(out - want).max()))
     assert np.array_equal(e.forward_host(x), want)             # ... into pageable memory as well
-    e.set_option("stream_host", 1)
+    e.set_option("stream_host", 0)                             # one copy each way
     pin_p.array[...] = -1.0
     assert np.array_equal(e.forward_host(pin_x.array, out=pin_p.array), want) and e.timing()["host_streamed"] == 0
+    e.set_option("stream_host", 1)
     # early hand-over (mdk_gru_stage_input / mdk_gru_forward_staged): same bits, no input copy inside the call
     tok = e.stage_input(pin_x.array.ctypes.data, B, T)
     pin_p.array[...] = -1.0
