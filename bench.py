@@ -832,7 +832,11 @@ def main():
         if traffic_doc:
             dom_traffic = traffic_doc.get("k_rec_fused_bytes_per_step") if "k_rec_fused" in dom["kernel"] else traffic_doc.get("k_rec_mfma_bytes_per_launch")
         result["roofline"] = {
-            "kernel": dom["kernel"] + " -- one launch = one layer pass over all (virtual) windows, both directions, every step"
+            "kernel": dom["kernel"] + (" -- one layer pass over all (virtual) windows, both directions, every step = TWO launches of the kernel: "
+                                       "steps [0, T/2) with HEAD = 1 (partial logits), [T/2, T) with HEAD = 2 (probabilities); "
+                                       "`avg_launch_ms` / `algorithmic_flop_per_launch` are those of the pair, each launch has half of both"
+                                       if fused_flags[0] & 512 else
+                                       " -- one launch = one layer pass over all (virtual) windows, both directions, every step")
                       + ("" if split["chunks"] == 1 else f"; the split scan runs {split['chunks'] * B} windows of {split['columns']} columns, the "
                          "algorithmic FLOP are those of the REAL columns (margins are overhead)"),
             "bound": "mfma", "achieved": dom["algorithmic_tflops"], "peak": peak, "unit": "TFLOP/s",

@@ -719,7 +719,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         if (nt <= 0) return;
         const size_t need = (size_t)n_wg * nt * 64;
         hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, src, m->xfrag, nb, T,
-                           Lp.K, nq, hp ? 1 : 0, n_wg, Lp.x_scale, m->oor_flag, t0, nt);
+                           Lp.K, nq, hp ? 1 : 0, n_wg, Lp.x_scale, m->oor_flag, t0, nt, sp ? *sp : SplitPlan{});
     };
 
     for (int l = 0; l < L; ++l) {
@@ -751,7 +751,18 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         // fp16 range) with it.  It reads all of x, so with slabs it is enqueued after the last of them.
         auto launch_gi_small = [&]() {
             const int tpb = 128;
-            hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, in,
+            const float *src = in;
+            if (sp && l == 0) {
+                // split scan: `in` is the REAL batch (k_pack_x maps the virtual windows onto it); the exact projection wants
+                // the virtual batch in memory -- gathered only if the range flag is up (unfused layer 0: always)
+                const int F = m->desc.num_features;
+                const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(in) % 8 == 0) ? 2 : 1;
+                const size_t n = (size_t)nb * T * F / vec;
+                hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
+                                   in, m->xv, *sp, F, vec, 0, T, cond);
+                src = m->xv;
+            }
+            hipLaunchKernelGGL(k_gi_small<16>, dim3(n_tiles, D, (T + tpb - 1) / tpb), dim3(768), 0, s, src,
                                Ld.w_ih_t, Ld.bias_gi, m->gi, nb, T, Ld.K, n_tiles, tpb, Ld.up_scale_rec, cond, 1);
         };
         if (l == 0) {
@@ -1162,18 +1173,13 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     // What stays exposed is the last launch's chunk; a shape that cannot be chunked leaves as one copy behind the forward.
     if (x_host)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
-    {
-        // float2 copies need 8-byte aligned rows: an even feature count and a caller's pointer that is not on an odd float
-        const int vec = (F % 2 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 8 == 0) ? 2 : 1;
-        const size_t n = cols * F / vec;
-        hipLaunchKernelGGL(k_split_gather, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, s,
-                           x_dev, m->xv, sp, (int)F, vec, 0, sp.Tv);
-    }
     HostIO io;
     io.p_host = probs_host;
     EvTimer tm{m, s};
     std::vector<hipEvent_t> out_done;      // (the last result chunks are still crossing PCIe while the certificate is computed)
-    rc = forward_pass(m, m->xv, Bv, sp.Tv, probs_dev, s, tm, probs_host ? &io : nullptr, &sp, &out_done);
+    // (x_dev is the REAL batch: layer 0's operands are packed straight from it, chunk by chunk; m->xv -- the virtual batch in
+    // memory -- is written only if the exact-projection fallback needs it)
+    rc = forward_pass(m, x_dev, Bv, sp.Tv, probs_dev, s, tm, probs_host ? &io : nullptr, &sp, &out_done);
     if (rc) return rc;
     hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
                        (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);

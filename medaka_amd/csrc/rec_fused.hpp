@@ -43,6 +43,9 @@
 
 namespace mdk {
 
+#ifndef MDK_FIN_REQ
+#define MDK_FIN_REQ 4      // HEAD = 2: the step of a strip under which the other direction's partial logits are requested
+#endif
 constexpr int kFusedSteps = 8;                         // scan steps per strip = rows 2 mt + tt of 4 MFMA row-tiles
 constexpr int kFusedMT = kFusedSteps / 2;
 __host__ __device__ inline constexpr size_t fused_lds_bytes(int KSTEPS, bool hp = false) { return (size_t)(hp ? 1 : 2) * kFusedMT * KSTEPS * 64 * 16; }
@@ -233,7 +236,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     // HEAD = 2: the other direction's partial logits of this wave's column, requested under step 6 of the strip (nothing
     // else is in flight then) and used at the top of the next one
     cgfloat *lp_other = (cgfloat *)(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40 + (2 * g) * 5 + cc);
-    float oth[2] = {0.f, 0.f}, lb = 0.f;
+    float oth[2] = {0.f, 0.f};
+    float lbs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // the classifier bias: wave-uniform, lives in scalar registers
+    if constexpr (FIN) {
+#pragma unroll
+        for (int cl = 0; cl < 5; ++cl) lbs[cl] = lin_b[cl];
+    }
     auto head_strip = [&](int hs) {
         const int s = hs * kFusedSteps + w8;
         const int t = reverse ? (T - 1 - s) : s;
@@ -267,12 +275,14 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             for (int q = 0; q < 2; ++q) {
                 float v = own[q];
                 if constexpr (DIN == 2) v = d == 0 ? own[q] + oth[q] : oth[q] + own[q];
-                v += lb;
+                float a[5];
+#pragma unroll
+                for (int cl = 0; cl < 5; ++cl) a[cl] = __shfl(v, (lane & 48) + cl) + lbs[cl];
+                v = a[0];
+#pragma unroll
+                for (int cl = 1; cl < 5; ++cl) v = c == cl ? a[cl] : v;
                 float res = v;
                 if (normalise) {
-                    float a[5];
-#pragma unroll
-                    for (int cl = 0; cl < 5; ++cl) a[cl] = __shfl(v, (lane & 48) + cl);
                     float mx = a[0];
 #pragma unroll
                     for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, a[cl]);
@@ -288,7 +298,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     };
     auto head_request = [&](int hs) {
         if constexpr (FIN) {
-            lb = ((cgfloat *)lin_b)[cc];
             if constexpr (DIN == 2) {
                 const int s = hs * kFusedSteps + w8;
                 const int t = reverse ? (T - 1 - s) : s;
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                 }
             }
             if (j % kIssue == 0 && j / kIssue < NPIECE) pc[j / kIssue] = piece_load(nstrip, j / kIssue);
-            if (j == 6) head_request(strip);
+            if (j == MDK_FIN_REQ) head_request(strip);
             // deferred store of the previous step's h (rec_mfma.hpp DS), unconditional: the first step of a launch writes its
             // incoming state (zero, or the resumed h) into its OWN slot, which the next step's store then overwrites
             const long back = step > s0 ? ostride : 0;

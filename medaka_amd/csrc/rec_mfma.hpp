@@ -485,7 +485,9 @@ static __global__ __launch_bounds__(256) void k_pack_x(
     const float *__restrict__ x,   // [B][T][I]
     half8 *__restrict__ xfrag,     // [n_wg][T][64]
     int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor,
-    int t_lo, int nt)              // columns [t_lo, t_lo + nt) of every window (the host path streams x in time slabs)
+    int t_lo, int nt,              // columns [t_lo, t_lo + nt) of every window (the host path streams x in time slabs)
+    SplitPlan sp)                  // sp.S > 1: B x T is the VIRTUAL batch of a split scan and x the real (sp.B, sp.T, I) one --
+                                   // virtual window v = k * sp.B + w is columns [sp.start[k], +T) of window w (scan_split.hpp)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_wg * nt * 64;
@@ -501,6 +503,11 @@ static __global__ __launch_bounds__(256) void k_pack_x(
     const int split = hp ? 0 : (row & 1);
     const int win = wg * 4 * nq + nq * g + q;
     const bool live = (q < nq) && (win < B);
+    size_t src = ((size_t)win * T + t) * I;
+    if (sp.S > 1 && live) {
+        const int k = win / sp.B;
+        src = ((size_t)(win - k * sp.B) * sp.T + sp.start[k] + t) * I;
+    }
     half8 v;
     bool bad = false;
 #pragma unroll
@@ -508,7 +515,7 @@ static __global__ __launch_bounds__(256) void k_pack_x(
         const int f = 8 * gq + i;
         float val = 0.f;
         if (live) {
-            if (f < I) val = x[((size_t)win * T + t) * I + f] * sx;
+            if (f < I) val = x[src + f] * sx;
             else if (f == I) val = sx;       // bias row of W_ih
         }
         bad |= !(fabsf(val) <= 60000.0f);

@@ -46,9 +46,12 @@ constexpr float kAuditTolHalf = 4.0e-4f;
 
 // x (B, T, F) -> xv (S*B, Tv, F), local columns [t_lo, t_lo + nt) of every virtual window: rows of nt*F floats, copied as
 // float2 (every row starts on a multiple of 2*F floats only when F is even: the odd case falls back to scalar copies
-// through `vec` = 1).  The whole batch is t_lo = 0, nt = Tv.
+// through `vec` = 1).  The whole batch is t_lo = 0, nt = Tv.  `cond`: run only if *cond != 0 -- the fused layer 0 packs its
+// operands straight from x (k_pack_x); the virtual batch is materialised only for the exact-projection fallback that an input
+// beyond fp16 range switches to on the device (k_pack_x raises the flag).
 static __global__ __launch_bounds__(256) void k_split_gather(const float *__restrict__ x, float *__restrict__ xv,
-                                                             SplitPlan p, int F, int vec, int t_lo, int nt) {
+                                                             SplitPlan p, int F, int vec, int t_lo, int nt, const int *__restrict__ cond) {
+    if (cond != nullptr && *cond == 0) return;
     const long row_elems = (long)nt * F / vec;
     const long total = (long)p.S * p.B * row_elems;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

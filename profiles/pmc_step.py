@@ -56,7 +56,8 @@ def main():
         cols = B * T
         vcols = 1000 * 2256          # the split scan's virtual batch at this shape: what the kernels really stream
         algo = {"k_rec_mfma<NQ=2,XIN=1,HP=0>": vcols * (1024 + 256),     # h out 1024 B/col + packed x 1 KB per (8 windows, step, dir)
-                "k_rec_fused<K=256,HEAD=1>": vcols * (2048 + 1024 + 40),  # both input directions read by both output directions, h out, partial logits
+                "k_rec_fused<K=256,HEAD=1>": vcols * (2048 + 1024 + 40) // 2,  # first half of the scan: both input directions read by both output directions, h out, partial logits out
+                "k_rec_fused<K=256,HEAD=2>": vcols * (2048 + 1024 + 40) // 2 + cols * 20,   # second half: the other direction's partial logits in, probabilities out
                 "k_rec_fused<K=256,HEAD=0>": vcols * (2048 + 1024),
                 "k_rec_mfma<NQ=2,XIN=0,HP=0>": vcols * 4096,             # (unfused: gi 2 x 1536 + h 1024)
                 "k_gi_gemm": vcols * (1024 + 3072), "k_head_tiled": vcols * 1024 + cols * 20,
@@ -70,8 +71,8 @@ def main():
                 total += b
         # one entry per layer pass (fused layer 0, layer 1), whatever work-group size the step ran with
         rec = [v["hbm_bytes_per_step"] for k, v in fams.items() if (k.startswith("k_rec_mfma<") or k.startswith("k_rec_fused<")) and "twin" not in k]
-        dom = [v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_fused<")]
-        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward at the engine's defaults (split scan: 5 chunks per window, margin 128 -> 1000 virtual windows of 2256 columns; layer 1's projection and the classifier's Linear fused into its recurrence kernel); rocprofv3 --pmc FETCH_SIZE / "
+        dom = [sum(v["hbm_bytes_per_step"] for k, v in fams.items() if k.startswith("k_rec_fused<"))]      # (one layer pass = its HEAD = 1 and HEAD = 2 launches)
+        traffic = {"config": f"B={B} T={T} (BASELINE configs[1]), one device-resident forward at the engine's defaults (split scan: 5 chunks per window, margin 128 -> 1000 virtual windows of 2256 columns; layer 1's projection, the classifier's Linear and the softmax fused into its recurrence kernel: HEAD = 1 for the first half of the scan, HEAD = 2 for the second); rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE in separate passes, summed over every dispatch of the step per kernel family; "
                              "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
                    "families": fams, "total_hbm_bytes_per_step": total,
