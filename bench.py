@@ -717,10 +717,10 @@ def main():
     # The box's power management is part of this number.  Straight after a stretch of device-resident work the 2-D DMA
     # copies that carry finished columns home run at a third of their rate for the next ~15 calls (150-200 ms; measured:
     # profiles/r4_experiments/README.md "host-to-host after a compute burst"), then settle -- a prediction run is in the settled
-    # state from its first second on.  So: the first calls are recorded as they come (`first_calls_ms`), `settle` more
-    # are run untimed, and the median is taken over the timed calls after those.
+    # state from its first second on.  So: the first calls are recorded as they come (`first_calls_ms`), untimed calls follow
+    # until `settle_s` seconds of host-path traffic have passed (at least 8 calls), and the median is taken over the timed calls after those.
     h2h_all, first_calls = {}, {}
-    settle = 24
+    settle_s, settle = 0.6, 0
     for vname, xv in variants:
         xb = Batch(counts_matrix=xv)
         h2h = []
@@ -731,7 +731,11 @@ def main():
             h2h.append(time.perf_counter() - t0)
         log(f'host-to-host batches, input {vname}')
         n_timed = max(5, args.host_reps)
-        dist.timed_steps(ranks, host_step, lambda: None, steps=n_timed, warmup=2 + settle)
+        t_settle = time.perf_counter()
+        while len(h2h) < 8 or ranks.max_over_ranks(time.perf_counter() - t_settle) < settle_s:      # (every rank leaves the loop together)
+            host_step()
+        settle = max(settle, len(h2h))
+        dist.timed_steps(ranks, host_step, lambda: None, steps=n_timed, warmup=2)
         h2h_all[vname] = (ranks.max_over_ranks(statistics.median(h2h[-n_timed:])), n_timed)
         first_calls[vname] = [round(1e3 * t, 3) for t in h2h[:6]]
         log(f'host-to-host, input {vname}: median {1e3 * h2h_all[vname][0]:.2f} ms (first calls: ' + " ".join(f"{1e3 * t:.1f}" for t in h2h[:6]) + ')')
@@ -771,7 +775,7 @@ def main():
         "sequential_scan": sequential,
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
-            "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2 + settle,
+            "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2 + settle, "settle_seconds": settle_s,
             "first_calls_ms": first_calls[primary],
             "frac_of_device_resident": (cols_per_step / h_med) / (value / ranks.world),
             "input": primary,

@@ -232,11 +232,15 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 
     // HEAD: partial logits of strip `hs`, one scan step per wave (the image of h after step s sits in slot (s + 1) % 8)
     typedef const __attribute__((address_space(1))) float cgfloat;
-    const int cc = c < 5 ? c : 4;
-    // HEAD = 2: the other direction's partial logits of this wave's column, requested under step 6 of the strip (nothing
+    // HEAD = 2 works on both windows of a lane at once: lanes 16 g + 0..4 finish window 2g, lanes 16 g + 8..12 window 2g + 1
+    // (one exp / quotient / store sequence instead of two: the sequence is ~200 VALU instructions at 4 cycles each, on
+    // every wave at the same moment)
+    const int cq = c & 7, qsel = c >> 3;
+    const int cc = cq < 5 ? cq : 4;
+    // the other direction's partial logits of this wave's column, requested under step MDK_FIN_REQ of the strip (nothing
     // else is in flight then) and used at the top of the next one
-    cgfloat *lp_other = (cgfloat *)(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40 + (2 * g) * 5 + cc);
-    float oth[2] = {0.f, 0.f};
+    cgfloat *lp_other = (cgfloat *)(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40 + (2 * g + qsel) * 5 + cc);
+    float oth = 0.f;
     float lbs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // the classifier bias: wave-uniform, lives in scalar registers
     if constexpr (FIN) {
 #pragma unroll
@@ -270,30 +274,28 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             }
         } else {
             // k_head_combine's arithmetic (head.hpp), operation for operation: (part_0 + part_1) + bias; largest; exp; the
-            // five terms summed in class order; quotient.  The 5 logits of a window sit in lanes 16 g + 0..4.
+            // five terms summed in class order; quotient.  Window 2g + 1's logits move to lanes 8..12 of the group first.
+            const float up = __shfl(own[1], lane - 8);
+            float v = qsel ? up : own[0];
+            if constexpr (DIN == 2) v = d == 0 ? v + oth : oth + v;
+            float a[5];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float v = own[q];
-                if constexpr (DIN == 2) v = d == 0 ? own[q] + oth[q] : oth[q] + own[q];
-                float a[5];
+            for (int cl = 0; cl < 5; ++cl) a[cl] = __shfl(v, (lane & 56) + cl) + lbs[cl];
+            v = a[0];
 #pragma unroll
-                for (int cl = 0; cl < 5; ++cl) a[cl] = __shfl(v, (lane & 48) + cl) + lbs[cl];
-                v = a[0];
+            for (int cl = 1; cl < 5; ++cl) v = cq == cl ? a[cl] : v;
+            float res = v;
+            if (normalise) {
+                float mx = a[0];
 #pragma unroll
-                for (int cl = 1; cl < 5; ++cl) v = c == cl ? a[cl] : v;
-                float res = v;
-                if (normalise) {
-                    float mx = a[0];
+                for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, a[cl]);
+                float sum = 0.f;
 #pragma unroll
-                    for (int cl = 1; cl < 5; ++cl) mx = fmaxf(mx, a[cl]);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int cl = 0; cl < 5; ++cl) sum += __expf(a[cl] - mx);
-                    res = __expf(v - mx) / sum;
-                }
-                const FinRow r = ftab[2 * g + q];
-                if (c < 5 && t >= r.lo && t < r.hi) probs[r.base + (long)t * 5 + c] = res;
+                for (int cl = 0; cl < 5; ++cl) sum += __expf(a[cl] - mx);
+                res = __expf(v - mx) / sum;
             }
+            const FinRow r = ftab[2 * g + qsel];
+            if (cq < 5 && t >= r.lo && t < r.hi) probs[r.base + (long)t * 5 + cq] = res;
         }
     };
     auto head_request = [&](int hs) {
@@ -301,8 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             if constexpr (DIN == 2) {
                 const int s = hs * kFusedSteps + w8;
                 const int t = reverse ? (T - 1 - s) : s;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) oth[q] = lp_other[(size_t)t * 40 + q * 5];
+                oth = lp_other[(size_t)t * 40];
             }
         }
     };
