@@ -519,8 +519,8 @@ struct HostIO {
     float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
 };
 
-// the streamed host path of a split call cuts the virtual windows' scans into phases (forward_pass): layer 0 fused, and
-// a virtual window long enough for that to be worth the launches
+// the streamed host path of a split call cuts the last layer's scan into launches (forward_pass): only for virtual windows
+// long enough for that to be worth them
 constexpr int kSplitStreamMinT = 512;
 
 static int pool_event(mdk_gru *m, hipEvent_t *out) {
@@ -665,7 +665,7 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
     const bool ablated = (abl != 0 && !hp && nq <= 2);
     const bool can_chunk_any = D == 2 && !ablated && T % (2 * kGemmSteps) == 0;
     const bool can_chunk = can_chunk_any && T >= 2048;
-    const bool can_chunk_sp = can_chunk_any && T >= kSplitStreamMinT;      // (run_split asked split_stream_ok first)
+    const bool can_chunk_sp = can_chunk_any && T >= kSplitStreamMinT;      // a split call's result can leave in column chunks
     const bool overlap_ok = m->opt_overlap && can_chunk && L >= 2 &&
                             (n_wg * D * m->opt_gpu_share <= kOvMaxWgs || m->opt_overlap == 2);   // only while the recurrence leaves CUs idle (2 = force)
     // Layers >= 1 in the throughput regime (every CU holds a recurrence work-group: nothing is idle to hide a projection
@@ -1139,10 +1139,6 @@ static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     if (m->layers[0].K > 16) return false;
     return plan_split_shape(B, T, m->opt_gpu_share, m->opt_scan_split, m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin,
                             m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass, p);
-}
-
-static bool split_stream_ok(const mdk_gru *m, int Tv) {
-    return m->opt_stream_host && m->opt_fuse_l0 && m->layers[0].wx_frag != nullptr && Tv >= kSplitStreamMinT && Tv % (2 * kGemmSteps) == 0;
 }
 
 static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,

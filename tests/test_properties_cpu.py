@@ -91,6 +91,12 @@ def test_bench_kernel_table_arithmetic():
     assert abs(step["algorithmic_gflop"] - 804352 * 2e6 / 1e9) < 1e-6
     assert abs(step["frac_issued_of_fp16_peak"] - step["issued_gflop"] / 6.2 / 2500.0) < 1e-12
     assert 0.4 < step["frac_issued_of_fp16_peak"] < 0.45
+    assert [e["kernel"].split(" ")[0] for e in k] == ["k_rec_mfma<XIN>", "k_rec_fused", "k_head_combine"]
+    # the scan's second half writes the probabilities itself (timing bit 9): no head kernel on the list, its bytes on the scan's
+    k1, _ = bench.kernel_table(([2.0], [4.0], [0.01], [0.005], [6.2]), 2 | 256 | 512, split, 200, 10000, False)
+    assert [e["kernel"].split(" ")[0] for e in k1] == ["k_rec_mfma<XIN>", "k_rec_fused"] and "softmax" in k1[1]["kernel"]
+    assert abs(k1[1]["hbm_algorithmic_gb"] - by["k_rec_fused"]["hbm_algorithmic_gb"] - 2e6 * 20 / 1e9) < 1e-9
+    assert k1[1]["issued_gflop"] == by["k_rec_fused"]["issued_gflop"]
     # the unfused latency regime: 4-window work-groups, GEMM and head as kernels of their own
     k2, step2 = bench.kernel_table(([6.6], [6.3], [3.6], [0.4], [13.0]), 0, {"chunks": 1, "columns": 10000}, 200, 10000, False)
     names = [e["kernel"].split(" ")[0] for e in k2]
