@@ -445,6 +445,17 @@ def test_logits_mode(gold, engines):
     e = engine.GruEngine(weight_set(gold, "x3"), normalise=False)
     ref = oracle.c_gru_forward(x, weight_set(gold, "x3"), normalise=False)
     assert np.abs(e.forward_host(x) - ref).max() <= 5e-5
+    # ... and through the fused last layer, whose second half delivers the logits itself (rec_fused.hpp HEAD = 2, no softmax):
+    # the bits of the combine kernel, the oracle's values
+    x = synth.counts_windows(9, 64, seed=5)
+    e.enable_timing(True)
+    e.set_option("rec_windows_per_tile", 8)
+    e.set_option("fuse_proj", 2)
+    out = e.forward_host(x)
+    assert e.timing()["fused_layers"] == (2 | 256 | 512), e.timing()
+    e.set_option("final_head", 0)
+    assert np.array_equal(e.forward_host(x), out) and e.timing()["fused_layers"] == (2 | 256)
+    assert np.abs(out - oracle.c_gru_forward(x, weight_set(gold, "x3"), normalise=False)).max() <= 5e-5
     e.close()
 
 
