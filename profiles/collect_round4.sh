@@ -29,7 +29,7 @@ if has rl; then
 fi
 if has prof; then
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru" -o gru -- python "$R/bench.py" --device-only --steps 5 --warmup 2 > "$OUT/kt_gru.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_gru" -o gru -- python "$R/bench.py" --device-only --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-5} > "$OUT/kt_gru.log" 2>&1
   cd "$R"
   db=$(find "$OUT/kt_gru" -name "*_results.db" | head -1)
   [ -n "$db" ] && python profiles/summarize.py "$db" "$OUT/kt_gru_kernel_stats.csv" > /dev/null
