@@ -12,12 +12,15 @@ time of K steps.  Multi-GPU = independent replicas on disjoint window shards, no
 the data path (weak scaling: per-GPU batch fixed).
 
 Also reported on the same JSON line:
-  host_to_host  the rate SURVEY.md section 8d defines: host tensor in -> host tensor out through
-                `model.predict_on_batch` (reference models.py:303-313), 2 warm-ups + median of >= 5
-                timed batches, with the input/output copies streamed under the recurrences
-  roofline      dominant kernel (k_rec_mfma, the GRU recurrence): algorithmic FLOP per launch
-                / hipEvent-measured launch duration vs the fp16 dense MFMA peak / 4 (the fp32-parity
-                split issues 4 fp16 MACs per algorithmic MAC); the native-fp32 fraction is kept beside it
+  host_to_host  (= metric_8d) the rate SURVEY.md section 8d defines: host tensor in -> host tensor out through
+                `model.predict_on_batch` (reference models.py:303-313): median of >= 5 timed batches after
+                0.6 s of untimed ones (the first six are on the line as they came: `first_calls_ms`)
+  fed_loop      the same inside the thread structure of the reference's inference loop
+  roofline      dominant kernel (k_rec_fused: layer 1's projection + recurrence + classifier head in one
+                kernel; k_rec_mfma on the sequential scan): algorithmic FLOP per layer pass / hipEvent-measured
+                duration vs the fp16 dense MFMA peak / the fp16 MACs the fp32-parity split issues per
+                algorithmic MAC (3.33; 4 for k_rec_mfma); one entry per hot kernel under `kernels`, the whole
+                forward under `step`; the native-fp32 fraction is kept beside it
   cpu_baseline  the reference's own CPU path (B in {10, 100, 200} x threads in
                 {1, 2, cpu_count}, 1 warm-up + median of 3, under a wall-clock cap) -- the unmodified
                 reference class when /root/reference is present, its PyTorch-CPU restatement otherwise
@@ -69,7 +72,7 @@ def parse():
                          "`value` / `host_to_host` are the aggregates of the K processes, `n_gpus` counts the ranks")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
-    ap.add_argument("--stream-host", type=int, default=None, help="host path: copies in time slabs under the recurrences (1, default), one copy each side (0), 2 = also a split call's result")
+    ap.add_argument("--stream-host", type=int, default=None, help="host path: 1 (default) = copies in time slabs under the recurrences / a split call's result under the second half of its last scan; 0 = one copy each side; 2 = a split call's result behind a side-stream head kernel (experiments)")
     ap.add_argument("--pinned-input", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--pageable-input", action="store_true",
                     help="host-to-host batches only from a pageable input tensor (the reference's collate) instead of the page-locked "
