@@ -118,7 +118,10 @@ int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weights, int n_
  * any B (last batch is short, medaka/common.py:903-916) and any T (the un-chunked B=1 second
  * pass, medaka/prediction.py:196-209).  Internally x is copied in and the probabilities out in time
  * slabs while the recurrences run (bidirectional models, T >= 2048, T % 16 == 0; otherwise one copy
- * each side); pageable and page-locked buffers are both accepted.
+ * each side); a call that runs as a split scan (option "scan_split") copies x in once, in front of the
+ * forward, and sends the probabilities home in column chunks under the second half of the last layer's
+ * scan (options "final_head", "stream_host"; mdk_gru_timing.host_streamed says what the last call did).
+ * Pageable and page-locked buffers are both accepted.
  */
 int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host);
 
