@@ -31,8 +31,8 @@
 // step j's image by the 8 W_lin fragments (4 k-steps x hi/lo: 8 MFMAs per wave and strip against 288 of projection) and
 // stores this direction's 5 partial logits of its 8 windows (160 bytes per (tile, t, direction)).  k_head_combine
 // (head.hpp) adds the two directions and the bias and takes the softmax: a 40-us kernel instead of the 0.41 ms
-// k_head_tiled pass over the activations -- and, unlike that one, small enough to run beside a recurrence that holds
-// every CU, which is what lets the host path send finished columns home while the scan is still running.
+// k_head_tiled pass over the activations.  (Not small enough to run BESIDE a recurrence that holds every CU, though: launched
+// next to one it finishes when the recurrence does, profiles/r4_experiments/README.md -- hence HEAD = 2 below.)
 // Same fp16x2 split as everywhere (h hi+lo times W hi+lo, fp32 accumulate): logits agree with the fp32 FMA head to ~1e-7
 // relative, not bit for bit.
 #pragma once
