@@ -61,7 +61,7 @@ def main():
                 "k_rec_fused<K=256,HEAD=0>": vcols * (2048 + 1024),
                 "k_rec_mfma<NQ=2,XIN=0,HP=0>": vcols * 4096,             # (unfused: gi 2 x 1536 + h 1024)
                 "k_gi_gemm": vcols * (1024 + 3072), "k_head_tiled": vcols * 1024 + cols * 20,
-                "k_head_combine": vcols * 40 + cols * 20, "k_pack_x": vcols * (40 + 256), "k_split_gather": (cols + vcols) * 40}
+                "k_head_combine": vcols * 40 + cols * 20, "k_pack_x": vcols * (40 + 256)}       # (k_split_gather is an empty launch unless the input leaves fp16 range)
         fams, total = {}, 0.0
         for fam in sorted(acc):
             if "FETCH_SIZE" in acc[fam] or "WRITE_SIZE" in acc[fam]:
