@@ -510,10 +510,12 @@ enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
 //        come from both ends towards the middle -- [0,T/16)+[15T/16,T) first, doubling -- as strided 2-D
 //        copies (one row of slab columns per window) into the natural (B,T,F) device layout; layer 0's
 //        recurrence is cut at the same boundaries and each piece waits only for its own slabs;
-//   out: the classifier head already runs in column chunks under the tail of the last recurrence; each
-//        chunk is copied out as soon as it exists (again 2-D: nt columns x nb windows).
+//   out: finished columns are copied out as soon as they exist (again 2-D: nt columns x nb windows) -- behind the chunks
+//        of a side-stream classifier head where the recurrence leaves CUs idle for one (sequential scan of a small
+//        batch), behind the launches of the last layer's second half where that half writes the probabilities itself
+//        (rec_fused.hpp HEAD = 2: split scans, batches that fill the chip).
 // 80 MB in + 40 MB out per 200 x 10000 batch cost 2.1 ms of PCIe time (profiles/r2_host_path_probe.txt);
-// what stays exposed is the first slab pair (10 MB) and the last head chunk.
+// what stays exposed is the first slab pair (10 MB; a split call: all of x) and the last chunk of columns.
 struct HostIO {
     const float *x_host = nullptr;   // (nb, T, F) of this pass, or null: x is already on the device
     float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
