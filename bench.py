@@ -704,7 +704,6 @@ def main():
                               "scan_split": split, "sequential": sequential,
                               "rec_ms_per_step": sum(rec_ms) / args.steps,
                               "rec_l0_ms": statistics.mean(rec_l0[-args.steps:]), "rec_l1_ms": statistics.mean(rec_l1[-args.steps:]),
-                              "rolled": bool(eng.timing().get("rolled")),
                               "gi_ms_per_step": statistics.mean(gi_ms[-args.steps:]),
                               "head_ms_per_step": statistics.mean(head_ms[-args.steps:])}), flush=True)
         ranks.close()

@@ -72,8 +72,7 @@ typedef struct {
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
                              "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both); bit 8: the classifier's Linear
                              ran inside the last layer's kernel as well ("fuse_head": head_ms is the combine kernel); bit 9: ... and the
-                             scan's second half wrote the probabilities itself ("final_head": no head kernel, head_ms ~ 0); bit 10: the
-                             fused projection was rolled under the recurrence steps ("roll_proj", rec_roll.hpp: the same bits) */
+                             scan's second half wrote the probabilities itself ("final_head": no head kernel, head_ms ~ 0) */
 } mdk_gru_timing;
 
 /* What the last forward did about splitting the scan (option "scan_split" below). */

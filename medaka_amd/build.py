@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MDK_LIB_OUT") or os.path.join(HERE, "libmedaka_amd.so")
 SOURCES = ["api.hip", "rl_api.hip"]
-HEADERS = ["common.hpp", "layout.hpp", "host_common.hpp", "rec_mfma.hpp", "rec_fused.hpp", "rec_roll.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
+HEADERS = ["common.hpp", "layout.hpp", "host_common.hpp", "rec_mfma.hpp", "rec_fused.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
            "rl_front.hpp", "lstm_wide.hpp", "scan_split.hpp",
            os.path.join("..", "..", "include", "medaka_amd.h")]
 

@@ -22,7 +22,6 @@
 #include "head.hpp"
 #include "rec_mfma.hpp"
 #include "rec_fused.hpp"
-#include "rec_roll.hpp"
 #include "scan_split.hpp"
 
 using namespace mdk;
@@ -71,7 +70,6 @@ struct mdk_gru {
     float lin_inv_scale = 1.f;  // 1 / (kActScale * their operand scale)
     float *lpart = nullptr;     // partial logits of the fused head [D][n_tiles][T][8][5]
     int opt_fuse_proj = 1;      // layers >= 1: projection fused into the recurrence (rec_fused.hpp): 0 off, 1 when the call fills the chip, 2 always
-    int opt_roll_proj = 1;      // ... and rolled UNDER the recurrence steps instead of alternating with them (rec_roll.hpp; fp32 parity, bidirectional)
     half8 *xfrag = nullptr;     // packed layer-0 input fragments
     size_t xfrag_cap = 0;
     int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
@@ -356,10 +354,6 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     if (const char *e = getenv("MDK_FUSE_HEAD")) m->opt_fuse_head = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_FINAL_HEAD")) m->opt_final_head = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_FUSE_PROJ")) m->opt_fuse_proj = std::min(std::max(atoi(e), 0), 2);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_roll<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)roll_lds_bytes(0)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_roll<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)roll_lds_bytes(1)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_roll<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)roll_lds_bytes(2)));
-    if (const char *e = getenv("MDK_ROLL")) m->opt_roll_proj = atoi(e) ? 1 : 0;
 
     *out = m;
     return MDK_OK;
@@ -402,8 +396,6 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "fuse_proj")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "fuse_proj must be 0 (off), 1 (auto) or 2 (always)");
         m->opt_fuse_proj = value;
-    } else if (!strcmp(key, "roll_proj")) {
-        m->opt_roll_proj = value ? 1 : 0;
     } else if (!strcmp(key, "overlap_gemm")) {
         m->opt_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);   // 0 off, 1 auto, 2 force (experiments)
     } else if (!strcmp(key, "deferred_store")) {
@@ -797,21 +789,6 @@ static int forward_pass(mdk_gru *m, const float *x, int nb, int T, float *probs,
         auto launch = [&](bool xin, const int *cnd, int want, bool fin = false) {
             if (fused_proj) {
                 const int hd = (fuse_head && l == L - 1) ? (fin ? 2 : 1) : 0;
-                if (m->opt_roll_proj && !hp && D == 2) {
-                    // the projection rolled under the recurrence steps (rec_roll.hpp): same arguments, same bits
-#define MDK_LAUNCH_ROLL(HD)                                                                                                  \
-    hipLaunchKernelGGL((k_rec_roll<HD>), rgrid, dim3(512), roll_lds_bytes(HD), s, in, Ld.wih_frag, Ld.bias_gi,              \
-                       Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi, Ld.up_scale_rec,       \
-                       kActScale, reverse_mask, rs0, rns, (const half8 *)m->wlin_frag, m->lin_inv_scale, m->lpart,          \
-                       (const float *)m->lin_b, probs, nb, (int)m->desc.normalise, sp ? *sp : SplitPlan{})
-                    if (hd == 2) MDK_LAUNCH_ROLL(2); else if (hd == 1) MDK_LAUNCH_ROLL(1); else MDK_LAUNCH_ROLL(0);
-#undef MDK_LAUNCH_ROLL
-                    if (hd) m->last.fused_layers |= 1 << 8;
-                    if (hd == 2) m->last.fused_layers |= 1 << 9;
-                    m->last.fused_layers |= 1 << l;
-                    m->last.fused_layers |= 1 << 10;
-                    return;
-                }
 #define MDK_LAUNCH_FUSED(KS, HD, HPF)                                                                                         \
     hipLaunchKernelGGL((k_rec_fused<KS, HD, HPF>), rgrid, dim3(512), fused_lds_bytes(KS, HPF), s, in, Ld.wih_frag, Ld.bias_gi, \
                        Ld.whh_frag, Ld.b_hn, outp, n_tiles, T, D, Ld.inv_scale_rec, Ld.inv_scale_gi, Ld.up_scale_rec,       \

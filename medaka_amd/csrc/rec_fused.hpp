@@ -417,7 +417,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             // incoming state (zero, or the resumed h) into its OWN slot, which the next step's store then overwrites
             const long back = step > s0 ? ostride : 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) *(op[q] - back) = hprev[q];
+            // (non-temporal: nobody reads h before the next layer, and 1 KB per column of it would otherwise pass through the L2
+            // the W_ih fragments want to stay in -- 6.40 -> 6.29 ms per forward, profiles/r5_experiments/README.md)
+            for (int q = 0; q < 2; ++q) __builtin_nontemporal_store(hprev[q], op[q] - back);
             // the piece requested two steps ago has arrived by now: split it and put it into the image (under the MFMAs)
             if (j >= 2 && (j - 2) % kIssue == 0 && (j - 2) / kIssue < NPIECE) piece_store((j - 2) / kIssue, pc[(j - 2) / kIssue]);
             __builtin_amdgcn_sched_barrier(0);

@@ -143,8 +143,7 @@ class GruEngine:
         n = t.n_layers
         return {"h2d_ms": t.h2d_ms, "gi_ms": list(t.gi_ms)[:n], "rec_ms": list(t.rec_ms)[:n],
                 "head_ms": t.head_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms,
-                "rec_launches": t.rec_launches, "fused_layers": t.fused_layers & 0x3ff, "rolled": bool(t.fused_layers & 0x400),
-                "host_streamed": t.host_streamed}
+                "rec_launches": t.rec_launches, "fused_layers": t.fused_layers, "host_streamed": t.host_streamed}
 
     def split(self):
         """What the last forward did about splitting the scan (include/medaka_amd.h `mdk_gru_split`)."""

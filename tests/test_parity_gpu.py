@@ -266,50 +266,6 @@ def test_multi_pass_with_overlap_agrees_bitwise(gold):
     e.close()
 
 
-@pytest.mark.parametrize("head", [0, 1, 2], ids=["head0", "head1", "head2"])
-def test_rolled_projection_agrees_bitwise(gold, head):
-    """Option "roll_proj" (rec_roll.hpp): the fused projection's MFMAs are issued UNDER the recurrence steps (two blocks of
-    18 per step) instead of in a phase of their own -- every accumulator still sees the same products in the same order, the
-    epilogue is the same fmaf at the consumer, the head the same MFMAs on the same fragments -- so whatever the head form
-    (none / partial logits / probabilities from the scan's second half), whole layers, resumed ones and split scans, the
-    result is BIT-IDENTICAL to k_rec_fused."""
-    st = weight_set(gold, "trained")
-    e = engine.GruEngine(st)
-    e.enable_timing(True)
-    e.set_option("rec_windows_per_tile", 8)
-    e.set_option("fuse_proj", 2)
-    e.set_option("fuse_head", 1 if head else 0)
-    e.set_option("final_head", 1 if head == 2 else 0)
-    e.set_option("scan_split", 0)
-    for B, T in ((13, 2304), (9, 8), (8, 16), (3, 1000), (40, 264), (17, 4096), (1, 24), (64, 512)):
-        x = synth.counts_windows(B, T, depth=40, seed=B * 1000 + T)
-        outs = {}
-        for roll in (0, 1):
-            e.set_option("roll_proj", roll)
-            outs[roll] = e.forward_host(x)            # host entry: with T >= 2048 the last layer runs in resumed pieces
-            t = e.timing()
-            assert t["rolled"] == bool(roll and T % 8 == 0), (B, T, roll, t)
-        assert np.array_equal(outs[0], outs[1]), (B, T, float(np.abs(outs[0] - outs[1]).max()))
-        if B * T < 40000:
-            _check(outs[1], oracle.c_gru_forward(x, st), what=f"rolled {B}x{T}")
-        # device entry: one launch per layer (or two: the final head cuts the scan at T/2)
-        xd = torch.from_numpy(x).cuda()
-        yd = torch.empty(B, T, 5, device="cuda")
-        e.forward_ptr(xd.data_ptr(), B, T, yd.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(yd.cpu().numpy(), outs[1]), (B, T)
-    # ... and as a split scan (virtual windows, chunk-local delivery of the final head)
-    e.set_option("scan_split", 1)
-    x = synth.counts_windows(24, 4096, depth=40, seed=99)
-    outs = {}
-    for roll in (0, 1):
-        e.set_option("roll_proj", roll)
-        outs[roll] = e.forward_host(x)
-        assert e.split()["chunks"] > 1 and e.timing()["rolled"] == bool(roll), (e.split(), e.timing())
-    assert np.array_equal(outs[0], outs[1])
-    e.close()
-
-
 @pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
 @pytest.mark.parametrize("bidirectional", [True, False], ids=["bi", "uni"])
 def test_fused_projection_agrees_bitwise(gold, bidirectional, half):
