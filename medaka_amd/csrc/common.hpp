@@ -61,6 +61,28 @@ __device__ __forceinline__ void store_run(float *p, typename FloatRun<N>::vec_t 
     *reinterpret_cast<typename FloatRun<N>::unaligned_t *>(p) = v;
 }
 
+// Buffer addressing: a wave-uniform base in four SGPRs + ONE 32-bit lane offset + a scalar (or immediate) offset per access.
+// Where a kernel's addresses differ by compile-time or wave-uniform amounts -- a scan's per-step blocks -- the 64-bit
+// per-lane pointer form costs vector instructions per access (64-bit adds, selects) in an in-order instruction stream whose
+// every cycle between two MFMAs is on the recurrence's critical path; in this form the stepping is scalar arithmetic.
+// The window is 2 GB from the base (num_records, raw buffer; out-of-range reads return 0, writes are dropped); word 3 is
+// gfx9's 32-bit-data descriptor.
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ floatx4 buf_load_floatx4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load_float(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// aux: 0 default cache policy, 2 = nt (non-temporal: streaming data nobody re-reads soon)
+template <int AUX = 0>
+__device__ __forceinline__ void buf_store_float(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AUX);
+}
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for global loads/stores
 // in flight (the gi prefetch ring and the h stores must stay in flight across steps).
 __device__ __forceinline__ void lds_barrier() {

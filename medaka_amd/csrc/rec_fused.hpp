@@ -79,9 +79,8 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 {
     constexpr bool FIN = HEAD == 2;
     constexpr int DIN = KSTEPS / 4;
-    constexpr int NP = DIN * 128;               // 8-float pieces per activation block
     constexpr int MT = kFusedMT;
-    constexpr int NPIECE = kFusedSteps * NP / 512;   // pieces per thread and strip
+    constexpr int NPIECE = kFusedSteps * DIN * 128 / 512;   // pieces (two 16-byte quads) per thread and strip
     static_assert(NPIECE == 2 || NPIECE == 4, "staging schedule below assumes 2 or 4 pieces per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *xs = reinterpret_cast<half8 *>(smem);            // [split 2][mt MT][KSTEPS][64 lanes]
@@ -89,6 +88,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     __shared__ __attribute__((aligned(16))) unsigned char hbuf[NIMG * kHBufBytes];
     struct FinRow { long base; int lo, hi; };        // HEAD = 2: window w of the tile delivers local columns [lo, hi) to probs + base + 5 t
     __shared__ FinRow ftab[FIN ? kTileWin : 1];
+    // HEAD: this direction's 8 W_lin fragments -- every wave multiplies its step's image by the same ones, once per strip;
+    // from LDS instead of eight L2 round trips at the top of every projection phase
+    __shared__ half8 wlds[HEAD ? 512 : 1];
     __builtin_amdgcn_s_setprio(MDK_REC_PRIO);
 
     const int tid = threadIdx.x;
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                 for (int sp = 0; sp < NS; ++sp) wf[ks][gate][sp] = wp[(size_t)((ks * 3 + gate) * 2 + sp) * 64];
     }
     for (int i = tid; i < NIMG * kHBufBytes / 4; i += 512) reinterpret_cast<uint32_t *>(hbuf)[i] = 0u;
+    if constexpr (HEAD != 0) wlds[tid] = wlin_frag[(size_t)d * 8 * 64 + tid];
     if constexpr (FIN) {
         if (tid < kTileWin) {
             const int win = tile * kTileWin + tid;
@@ -143,59 +146,70 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) bv[nt] = bias[(size_t)d * kG + nt * kH + u] * os;
 
-    const long tstep = reverse ? -1 : 1;
     const int s_end = s0 + ns;
-    const int t_first = reverse ? (T - 1 - s0) : s0;
-    // (explicitly GLOBAL pointers: through the select of the deferred store's address hipcc otherwise loses the address
-    // space in some instantiations and emits FLAT stores, which count on lgkmcnt as well -- every wait for a staged piece
-    // then becomes vmcnt(0); seen in the ISA of the half-precision build, and in round 3's two-tile experiment)
-    typedef __attribute__((address_space(1))) float gfloat;
-    gfloat *op[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) op[q] = (gfloat *)(out + act_block(D, tile, T, t_first) + act_in_block(d, w8, q, lane));
-    const long ostride = tstep * (long)(D * 1024);
+    // Every HBM address of the scan in the buffer form (common.hpp): wave-uniform base + one lane offset + a scalar that
+    // follows the step -- no vector instruction per access in the step's in-order stream.
+    // This layer's output: the block of column t at t * D * 4096 bytes, this lane's two values 256 bytes apart.
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + act_block(D, tile, T, 0));
+    const unsigned ovoff = (unsigned)act_in_block(d, w8, 0, lane) * 4u;
+    const int obytes = D * 4096;
+    auto ocol = [&](int s) { return (unsigned)((reverse ? (T - 1 - s) : s) * obytes); };     // scan step -> byte offset of its column
     float hprev[2] = {0.f, 0.f};
 
     const int rd_off = g * kHGroupStride + c * 16;
     const int wr_off = (w8 >> 1) * kHKStride + (2 * (w8 & 1) + (c >> 3)) * kHGroupStride + (4 * g) * 16 + (c & 7) * 2;
 
-    // ---- staging of a strip's activations (the k_gi_gemm staging, one piece at a time; scan step tau of the strip is
-    // row 2 mt + tt = tau of the M-tile whatever the direction: a reversed scan stages its columns in descending order)
-    const float *in_tile = act_in + act_block(DIN, tile, T, 0);
+    // ---- staging of a strip's activations.  The image is the k_gi_gemm one (scan step tau of the strip is row 2 mt + tt = tau
+    // of the M-tile whatever the direction: a reversed scan stages its columns in descending order); the REQUESTS are laid
+    // out for the memory pipe: a wave's request is one contiguous KB -- lane l takes the 16-byte quad tid of a step's block --
+    // instead of the two halves of a lane's own 32-byte piece (every request then touched all 16 lines of a 2 KB span and
+    // used half of each; the eight requests per thread and strip cost 9 % of the kernel, profiles/r5_experiments/README.md).
+    // A quad is 4 consecutive units of one window: half of one 8-slot k-group of its A-fragment row (an 8-byte LDS store).
+    const __amdgpu_buffer_rsrc_t irsrc = make_rsrc(act_in + act_block(DIN, tile, T, 0));
     struct Piece { floatx4 v0, v1; };
+    constexpr int CPS = DIN * 256;                  // 16-byte quads of one column's activation block
+    auto quad_pos = [&](int it, int l, int &tau, int &c9) {
+        const int C = (it * 2 + l) * 512 + tid;
+        tau = C / CPS; c9 = C % CPS;
+    };
     auto piece_load = [&](int strip, int it) {
-        const int P = it * 512 + tid;
-        const int tau = P / NP, j = P % NP;
-        const int gg = j & 3, qq = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
-        const int piece = chunk * 16 + qq * 8 + gg * 2 + half;
-        const int s = strip * kFusedSteps + tau;
-        const int t = reverse ? (T - 1 - s) : s;
-        const float *src = in_tile + (size_t)t * (DIN * 1024) + piece * 8;
         Piece p;
-        p.v0 = *reinterpret_cast<const floatx4 *>(src);
-        p.v1 = *reinterpret_cast<const floatx4 *>(src + 4);
+        int tau, c9;
+        quad_pos(it, 0, tau, c9);
+        { const int s = strip * kFusedSteps + tau; const int t = reverse ? (T - 1 - s) : s;
+          p.v0 = buf_load_floatx4(irsrc, (unsigned)c9 * 16u, (unsigned)(t * (DIN * 4096))); }
+        quad_pos(it, 1, tau, c9);
+        { const int s = strip * kFusedSteps + tau; const int t = reverse ? (T - 1 - s) : s;
+          p.v1 = buf_load_floatx4(irsrc, (unsigned)c9 * 16u, (unsigned)(t * (DIN * 4096))); }
         return p;
     };
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     auto piece_store = [&](int it, Piece p) {
         // the request stays in flight until HERE: without this the compiler multiplies by a_scale right behind the load
         // and waits for it in the step that issued it (seen in the ISA: vmcnt(0) under the next MFMAs)
         asm volatile("" : "+v"(p.v0), "+v"(p.v1));
-        const int P = it * 512 + tid;
-        const int tau = P / NP, j = P % NP;
-        const int gg = j & 3, qq = (j >> 2) & 1, half = (j >> 3) & 1, chunk = j >> 4;
-        const float v[8] = {p.v0[0], p.v0[1], p.v0[2], p.v0[3], p.v1[0], p.v1[1], p.v1[2], p.v1[3]};
-        half8 hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            _Float16 a, b;
-            split_f16(v[i] * a_scale, a, b);
-            hi[i] = a; lo[i] = b;
+        for (int l = 0; l < 2; ++l) {
+            int tau, c9;
+            quad_pos(it, l, tau, c9);
+            const floatx4 v = l ? p.v1 : p.v0;
+            // block offset 4 c9 floats = act_in_block(chunk, q, lane' = 16 g + c): units c .. c + 3 of window 2 g + q
+            const int cl = (c9 & 3) * 4, gg = (c9 >> 2) & 3, qq = (c9 >> 4) & 1, chunk = c9 >> 5;
+            half4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 a, b;
+                split_f16(v[i] * a_scale, a, b);
+                hi[i] = a; lo[i] = b;
+            }
+            const int row = 4 * gg + 2 * qq + (tau & 1), mt = tau >> 1;
+            const int k8 = chunk * 2 + (cl >> 3), ks = k8 >> 2;
+            const int slot = (k8 & 3) * 16 + row;
+            const int hb = (cl >> 2) & 1;                  // which half of the row's 8 k-slots
+            *reinterpret_cast<half4 *>(reinterpret_cast<unsigned char *>(&xs[((0 * MT + mt) * KSTEPS + ks) * 64 + slot]) + 8 * hb) = hi;
+            if constexpr (!HP)
+                *reinterpret_cast<half4 *>(reinterpret_cast<unsigned char *>(&xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot]) + 8 * hb) = lo;
         }
-        const int row = 4 * gg + 2 * qq + (tau & 1), mt = tau >> 1;
-        const int k8 = chunk * 2 + half, ks = k8 >> 2;
-        const int slot = (k8 & 3) * 16 + row;
-        xs[((0 * MT + mt) * KSTEPS + ks) * 64 + slot] = hi;
-        if constexpr (!HP) xs[((1 * MT + mt) * KSTEPS + ks) * 64 + slot] = lo;
     };
 
     const int strip0 = s0 / kFusedSteps, strip1 = s_end / kFusedSteps;
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     if (s0 > 0) {   // resume: h of scan step s0 - 1 from the output, and its fp16 image (as k_rec_mfma)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float h = *(op[q] - ostride);
+            const float h = buf_load_float(orsrc, ovoff + q * 256, ocol(s0 - 1));
             hprev[q] = h;
             _Float16 hi, lo;
             split_f16(h * kActScale, hi, lo);
@@ -231,7 +245,6 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const half8 *wp = wihfrag + ((size_t)(d * 8 + w8) * KSTEPS) * 6 * 64 + lane;
 
     // HEAD: partial logits of strip `hs`, one scan step per wave (the image of h after step s sits in slot (s + 1) % 8)
-    typedef const __attribute__((address_space(1))) float cgfloat;
     // HEAD = 2 works on both windows of a lane at once: lanes 16 g + 0..4 finish window 2g, lanes 16 g + 8..12 window 2g + 1
     // (one exp / quotient / store sequence instead of two: the sequence is ~200 VALU instructions at 4 cycles each, on
     // every wave at the same moment)
@@ -239,7 +252,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
     const int cc = cq < 5 ? cq : 4;
     // the other direction's partial logits of this wave's column, requested under step MDK_FIN_REQ of the strip (nothing
     // else is in flight then) and used at the top of the next one
-    cgfloat *lp_other = (cgfloat *)(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40 + (2 * g + qsel) * 5 + cc);
+    const __amdgpu_buffer_rsrc_t lorsrc = make_rsrc(lpart + ((size_t)(D - 1 - d) * n_tiles + tile) * T * 40);   // the other direction's partial logits
+    const __amdgpu_buffer_rsrc_t lprsrc = make_rsrc(lpart + ((size_t)d * n_tiles + tile) * T * 40);             // this direction's
+    const unsigned lovoff = (unsigned)(((2 * g + qsel) * 5 + cc) * 4);
     float oth = 0.f;
     float lbs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // the classifier bias: wave-uniform, lives in scalar registers
     if constexpr (FIN) {
@@ -250,13 +265,13 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
         const int s = hs * kFusedSteps + w8;
         const int t = reverse ? (T - 1 - s) : s;
         const unsigned char *img = hbuf + ((w8 + 1) & 7) * kHBufBytes + rd_off;
-        const half8 *wl = wlin_frag + (size_t)d * 8 * 64 + lane;
+        const half8 *wl = wlds + lane;
         floatx4 la = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const half8 a = *reinterpret_cast<const half8 *>(img + ks * kHKStride);
-            la = mfma16(a, wl[(size_t)(ks * 2 + 0) * 64], la);
-            if constexpr (!HP) la = mfma16(a, wl[(size_t)(ks * 2 + 1) * 64], la);
+            la = mfma16(a, wl[(ks * 2 + 0) * 64], la);
+            if constexpr (!HP) la = mfma16(a, wl[(ks * 2 + 1) * 64], la);
         }
         float own[2];
         if constexpr (HP) {
@@ -268,9 +283,9 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
         }
         if constexpr (!FIN) {
             if (c < 5) {
-                float *dst = lpart + (((size_t)d * n_tiles + tile) * T + t) * 40 + (2 * g) * 5 + c;
-                dst[0] = own[0];
-                dst[5] = own[1];
+                const unsigned vo = (unsigned)(((2 * g) * 5 + c) * 4);
+                buf_store_float(own[0], lprsrc, vo, (unsigned)(t * 160));
+                buf_store_float(own[1], lprsrc, vo + 20, (unsigned)(t * 160));
             }
         } else {
             // k_head_combine's arithmetic (head.hpp), operation for operation: (part_0 + part_1) + bias; largest; exp; the
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             if constexpr (DIN == 2) {
                 const int s = hs * kFusedSteps + w8;
                 const int t = reverse ? (T - 1 - s) : s;
-                oth = lp_other[(size_t)t * 40];
+                oth = buf_load_float(lorsrc, lovoff, (unsigned)(t * 160));
             }
         }
     };
@@ -415,11 +430,11 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             if (j == MDK_FIN_REQ) head_request(strip);
             // deferred store of the previous step's h (rec_mfma.hpp DS), unconditional: the first step of a launch writes its
             // incoming state (zero, or the resumed h) into its OWN slot, which the next step's store then overwrites
-            const long back = step > s0 ? ostride : 0;
+            const unsigned so_prev = ocol(step > s0 ? step - 1 : step);
 #pragma unroll
             // (non-temporal: nobody reads h before the next layer, and 1 KB per column of it would otherwise pass through the L2
             // the W_ih fragments want to stay in -- 6.40 -> 6.29 ms per forward, profiles/r5_experiments/README.md)
-            for (int q = 0; q < 2; ++q) __builtin_nontemporal_store(hprev[q], op[q] - back);
+            for (int q = 0; q < 2; ++q) buf_store_float<2>(hprev[q], orsrc, ovoff + q * 256, so_prev);
             // the piece requested two steps ago has arrived by now: split it and put it into the image (under the MFMAs)
             if (j >= 2 && (j - 2) % kIssue == 0 && (j - 2) / kIssue < NPIECE) piece_store((j - 2) / kIssue, pc[(j - 2) / kIssue]);
             __builtin_amdgcn_sched_barrier(0);
@@ -468,13 +483,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
                     *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q) * 16) = hi;
                     *reinterpret_cast<_Float16 *>(hbuf + nxt + wr_off + (2 * q + 1) * 16) = lo;
                 }
-                op[q] += ostride;
             }
             lds_barrier();
         }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *(op[q] - ostride) = hprev[q];      // the last step's h
+    for (int q = 0; q < 2; ++q) buf_store_float<2>(hprev[q], orsrc, ovoff + q * 256, ocol(s_end - 1));      // the last step's h
     if constexpr (HEAD) head_strip(strip1 - 1);                      // (the last step's barrier made its image visible)
 }
 
