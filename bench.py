@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
+    ap.add_argument("--extra-half", type=int, default=1,
+                    help="1 (default): the fp32-parity line also carries `extra.half`, the same batch with model.half() -- what the "
+                         "reference CLI selects on a GPU unless --full_precision (prediction.py:164-168); 0 = skip")
     ap.add_argument("--deferred-store", type=int, default=None, help="recurrence: store h_t from inside step t+1")
     ap.add_argument("--scan-split", type=int, default=None,
                     help="split scan (include/medaka_amd.h \"scan_split\"): default = the engine's (1, auto); 0 = the sequential scan "
@@ -152,14 +155,15 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
                 ref = np.load(outp)
     if not table:
         return ({"value": None, "unit": "pileup columns/s", "cores": 0, "kind": kind, "not_run": skipped,
-                 "sample": "no configuration finished inside the wall-clock cap"}, None)
+                 "sample": "no configuration finished inside the wall-clock cap"}, None, None)
     best = max(table, key=lambda r: r["columns_per_s"])
     base = {"value": best["columns_per_s"], "unit": "pileup columns/s", "cores": best["threads"], "kind": kind,
             "host_cores_available": cores, "os_cpu_count": os.cpu_count(), "table": table, "not_run": skipped,
             "wall_clock_cap_s": budget_s,
             "passes": best["passes"],
-            "sample": f"best of the BASELINE.md section-4 grid that fits {budget_s:.0f} s: B={best['batch']} x {T} columns, "
-                      f"{best['threads']} torch threads, fp32 PyTorch-CPU, median of {best['passes']} timed pass(es) after a warm-up; kind = "
+            "sample": f"{best['passes']} timed pass(es) (median) after a warm-up of B={best['batch']} x {T} columns on {best['threads']} torch threads "
+                      f"(the box shows os.cpu_count() = {os.cpu_count()}, {cores} usable), fp32 PyTorch-CPU: the best cell of the BASELINE.md "
+                      f"section-4 grid that fits {budget_s:.0f} s of wall clock; kind = "
                       + ("reference: the unmodified reference GRUModel.predict_on_batch (/root/reference present)" if kind == "reference" else
                          "port: the three torch calls of reference gru.py:66-71 restated (nn.GRU + Linear + softmax; /root/reference does not "
                          "exist on the GPU box)")}
@@ -167,7 +171,7 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
     parity = {"max_abs_dp": float(np.abs(probs_sample[:n] - ref).max()),
               "argmax_identical": bool((probs_sample[:n].argmax(-1) == ref.argmax(-1)).all()),
               "tolerance": 1e-4, "columns_checked": int(n * T)}
-    return base, parity
+    return base, parity, ref
 
 
 class LoopSample:
@@ -567,6 +571,116 @@ def main_rl(args, emit=True):
     return result if ranks.rank == 0 else None
 
 
+def summary_of(result):
+    """The figures of the line in < 1500 characters, for readers that keep only its tail (every value is also further up,
+    with its definition): rates in M columns/s, times in ms."""
+    def g(d, *path, scale=1.0, nd=1):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return round(d * scale, nd) if isinstance(d, (int, float)) and not isinstance(d, bool) else d
+    M = 1e-6
+    sp = result.get("scan_split") or {}
+    out = {"unit": "M columns/s (ms)",
+           "device_resident": g(result, "value", scale=M), "ms_per_step": g(result, "ms_per_step", nd=3),
+           "metric_8d": g(result, "metric_8d", "value", scale=M), "metric_8d_ms": g(result, "metric_8d", "ms_per_batch_median", nd=2),
+           "first_calls_ms": g(result, "host_to_host", "first_calls_ms"),
+           "fed_loop": g(result, "fed_loop", "value", scale=M), "pcie_diet": g(result, "pcie_diet_columns_per_s", scale=M),
+           "sequential_scan": g(result, "sequential_scan", "value", scale=M),
+           "value_at_learned_margin": g(result, "value_at_learned_margin", "value", scale=M),
+           "value_at_margin_256": g(result, "value_at_margin_256", "value", scale=M),
+           "scan_split": {k: (float(f"{sp[k]:.3g}") if isinstance(sp.get(k), float) else sp.get(k)) for k in ("chunks", "margin", "status", "max_delta")},
+           "roofline_frac": g(result, "roofline", "frac", nd=4), "roofline_frac_issued": g(result, "roofline", "frac_issued", nd=4),
+           "parity_max_abs_dp": g(result, "parity", "max_abs_dp", nd=9), "cpu_baseline": g(result, "cpu_baseline", "value", scale=M, nd=4),
+           "cpu_cores": g(result, "cpu_baseline", "cores")}
+    h = (result.get("extra") or {}).get("half") or {}
+    if h:
+        out["half"] = {"value": g(h, "value", scale=M), "ms_per_step": g(h, "ms_per_step", nd=3), "metric_8d": g(h, "metric_8d", "value", scale=M),
+                       "fed_loop": g(h, "fed_loop", "value", scale=M), "max_abs_dp": g(h, "parity", "max_abs_dp", nd=9),
+                       "argmax_identical_columns": g(h, "parity", "argmax_identical_columns"), "columns_checked": g(h, "parity", "columns_checked"),
+                       "split": g(h, "scan_split", "status"), "roofline_frac": g(h, "roofline", "frac", nd=4), "error": h.get("error")}
+    r = (result.get("extra") or {}).get("rl384") or {}
+    if r:
+        out["rl384"] = {"value": g(r, "value", scale=M, nd=3), "ms_per_step": g(r, "ms_per_step", nd=2),
+                        "metric_8d": g(r, "host_to_host", "value", scale=M, nd=3), "parity": g(r, "parity", "max_abs_dp", nd=9), "error": r.get("error")}
+    return out
+
+
+def half_section(model, eng, x_dev, x_host, B, T, ranks, dev, args, ref_probs):
+    """What `medaka inference` runs on a GPU BY DEFAULT (reference prediction.py:164-168: model.half() unless
+    --full_precision) on the same batch, in the same process: device-resident rate, host-to-host, the fed
+    loop, the split certificate, the dominant kernel against the fp16 peak, and parity of the full batch against the
+    fp32 PyTorch-CPU result of this run's cpu_baseline."""
+    import numpy as np
+    import torch
+    from medaka_amd import dist
+    from medaka_amd.torch_ext import Batch
+    model.half()
+    eng.enable_timing(True)
+    cols = B * T
+    out = {}
+
+    def step():
+        with torch.inference_mode():
+            out["y"] = model.forward(x_dev)
+    step(); torch.cuda.synchronize(dev)               # first call at this precision: audited against the sequential scan
+    first = eng.split()
+    rec0, rec1, gi, head, total, flags = [], [], [], [], [], [0]
+
+    def step_timed():
+        step()
+        t = eng.timing()
+        rec0.append(t["rec_ms"][0]); rec1.append(t["rec_ms"][1] if len(t["rec_ms"]) > 1 else 0.0)
+        gi.append(sum(t["gi_ms"])); head.append(t["head_ms"]); total.append(t["total_ms"]); flags[0] = t["fused_layers"]
+    n = max(5, args.steps)
+    elapsed, _ = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev), steps=n, warmup=2)
+    split = eng.split()
+    res = {"what": "model.half() -- the reference CLI's GPU default (prediction.py:164-168) -- same batch, same process: fp16 operands, "
+                   "fp32 accumulate, single product (k_rec_fused<HP>)",
+           "value": ranks.world * cols * n / elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * elapsed / n, "steps": n, "warmup": 2,
+           "scan_split": {k: split[k] for k in ("chunks", "columns", "margin", "status", "max_delta", "fallbacks")},
+           "first_call_audit_max_dp": first["audit_max_dp"], "first_call_audited": first["audited"]}
+    kernels, step_level = kernel_table((rec0[-n:], rec1[-n:], gi[-n:], head[-n:], total[-n:]), flags[0], split, B, T, True)
+    dom = max(kernels, key=lambda e: e["ms_per_step"])
+    res["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["algorithmic_tflops"], "peak": PEAK_F16_DENSE_TFLOPS,
+                       "unit": "TFLOP/s", "frac": dom["algorithmic_tflops"] / PEAK_F16_DENSE_TFLOPS, "frac_issued": dom["frac_issued_of_fp16_peak"],
+                       "avg_launch_ms": dom["ms_per_step"], "launches_timed": n,
+                       "peak_note": "fp16 dense MFMA peak, undivided: half precision issues one fp16 MAC per algorithmic MAC",
+                       "kernels": kernels, "step": step_level}
+    # host tensor in -> host tensor out, as the fp32 line measures it
+    eng.enable_timing(False)
+    xb = Batch(counts_matrix=torch.from_numpy(x_host).pin_memory())
+    h2h = []
+    t_settle = time.perf_counter()
+    while len(h2h) < 8 or time.perf_counter() - t_settle < 0.6:
+        t0 = time.perf_counter(); p = model.predict_on_batch(xb); h2h.append(time.perf_counter() - t0)
+    first_calls = [round(1e3 * t, 3) for t in h2h[:6]]
+    timed = []
+    for _ in range(max(5, args.host_reps)):
+        t0 = time.perf_counter(); p = model.predict_on_batch(xb); timed.append(time.perf_counter() - t0)
+    med = statistics.median(timed)
+    res["metric_8d"] = {"value": ranks.world * cols / med, "unit": "pileup columns/s", "ms_per_batch_median": 1e3 * med,
+                        "timed_batches": len(timed), "first_calls_ms": first_calls}
+    probs = p.numpy()
+    if ref_probs is not None:
+        k = ref_probs.shape[0]
+        res["parity"] = {"max_abs_dp": float(np.abs(probs[:k] - ref_probs).max()),
+                         "argmax_identical_columns": int((probs[:k].argmax(-1) == ref_probs.argmax(-1)).sum()),
+                         "columns_checked": int(k * T), "tolerance": 1e-4,
+                         "against": "fp32 PyTorch-CPU result of cpu_baseline (the same windows), split scan on"}
+    if args.loop_batches > 2 and ranks.world == 1:
+        from medaka_amd import torch_ext
+        windows = loop_windows(T, args.depth, 4321)
+        fast = lambda data: torch_ext.Batch.collate(data)
+        fed_loop(model, windows, B, 3, fast, warm=1)
+        fl = fed_loop(model, windows, B, args.loop_batches, fast)
+        res["fed_loop"] = {k: fl[k] for k in ("value", "ms_per_batch", "predict_ms_median", "collate_ms_median", "timed_batches")}
+    log(f"half precision: {res['value'] / 1e6:.1f} M columns/s device-resident ({res['ms_per_step']:.2f} ms), "
+        f"{res['metric_8d']['value'] / 1e6:.1f} M host-to-host, split {split['status']}, parity {res.get('parity', {}).get('max_abs_dp')}")
+    return res
+
+
 def main():
     args = parse()
     if args.procs_per_gpu > 1 and "WORLD_SIZE" not in os.environ:
@@ -686,6 +800,22 @@ def main():
         sequential = {"value": ranks.world * cols_per_step * 3 / seq_elapsed, "unit": "pileup columns/s",
                       "ms_per_step": 1e3 * seq_elapsed / 3, "steps": 3}
 
+    learned = None
+    if split["chunks"] > 1 and not args.device_only and args.scan_split is None and args.scan_split_margin is None:
+        # the margin is learned per model (include/medaka_amd.h "scan_split_adapt"): let the engine finish learning here, outside
+        # every timed region -- a smaller margin on trial that is rejected costs its call a second forward -- then time 3 steps
+        seen = [split["margin"]]
+        for _ in range(24):
+            step()
+            seen.append(eng.split()["margin"])
+        torch.cuda.synchronize(dev)
+        l_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
+        l_split = eng.split()
+        learned = {"value": ranks.world * cols_per_step * 3 / l_elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * l_elapsed / 3, "steps": 3,
+                   "margin": l_split["margin"], "chunks": l_split["chunks"], "columns": l_split["columns"], "status": l_split["status"],
+                   "margins_tried": sorted(set(seen), reverse=True), "rejected_trials": l_split["fallbacks"] - split["fallbacks"],
+                   "what": "after 24 more calls: the margin this model settles at (a rung of 64 .. 512 down while the junction differences sit "
+                           "at the noise floor, a rejected trial goes back for good); the weights of this line need 128"}
     at_margin_256 = None
     if split["chunks"] > 1 and not args.device_only and (args.scan_split_margin or 128) < 256:
         # what a model that needs twice the default margin would run at (the margin is the split scan's price)
@@ -773,7 +903,7 @@ def main():
                                   + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
         "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
-                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-17; 2^-10 in half precision); the model's first call "
+                           "(max_delta = largest |h_warm - h_carried|, threshold 2^-18; 2^-10 in half precision); the model's first call "
                            "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp)"
                            if split["chunks"] > 1 else "sequential scan"),
         "sequential_scan": sequential,
@@ -798,10 +928,17 @@ def main():
     result["metric_8d"] = {"value": result["host_to_host"]["value"], "unit": "pileup columns/s",
                            "ms_per_batch_median": result["host_to_host"]["ms_per_batch_median"],
                            "what": "SURVEY.md section 8d's metric: columns / wall time of predict_on_batch calls, host tensor in -> host tensor out "
-                                   "(= host_to_host.value; `value` above is the device-resident rate the bench contract asks for)"}
+                                   "(= host_to_host.value).  `value` above is the device-resident rate: this build's task statement fixes `value` as "
+                                   "\"whole-job throughput with inputs already resident in HBM when the timed region starts\" and rules the "
+                                   "PCIe-inclusive rate out of it; neither BASELINE.json nor SURVEY.md says that, SURVEY 8d asks for THIS figure"}
+    result["value_basis"] = "device-resident (inputs in HBM at the start of the timed region); SURVEY 8d's host-to-host rate is `metric_8d`"
+
+    if learned:
+        result["value_at_learned_margin"] = learned
     if at_margin_256:
         result["value_at_margin_256"] = at_margin_256
     shared_loop = None
+    ref_probs = None
     if args.shared_gpu and ranks.world > 1 and args.loop_batches > 2:
         # K processes per GPU, each running the whole fed loop (loader threads -> engine collate -> predict_on_batch ->
         # writer): the deployment `medaka_amd.launch --procs-per-gpu K` produces; aggregate = sum over the processes
@@ -856,6 +993,8 @@ def main():
                     "fp16 hi+lo operands: 3 products in the projection, 4 in the recurrence); `frac_issued` counts every MFMA the kernel "
                     f"executes (row padding, margin columns) against the undivided {PEAK_F16_DENSE_TFLOPS:.0f}; a native fp32-MFMA kernel would be capped at "
                     f"{PEAK_F32_MATRIX_TFLOPS} TFLOP/s, of which this launch reaches {dom['algorithmic_tflops'] / PEAK_F32_MATRIX_TFLOPS:.2f}",
+            "peak_note": f"{peak:.0f} TF = {PEAK_F16_DENSE_TFLOPS / 1000:.1f} PF fp16 dense MFMA / {issue_factor:.2f} (fp16 MACs issued per algorithmic MAC for fp32 parity); "
+                         "not a hardware number -- `frac_issued` is against the undivided hardware peak",
             "frac_of_f32_matrix_peak": dom["algorithmic_tflops"] / PEAK_F32_MATRIX_TFLOPS,
             "kernels": kernels, "step": step_level,
             "pmc": pmc_summary_r4() if (B == 200 and T == 10000 and not args.half and split["chunks"] > 1 and fused1) else None,
@@ -866,7 +1005,7 @@ def main():
         }
         if args.cpu_budget > 0 and ranks.world == 1:   # the CPU baseline is a single-GPU-run figure
             probs = out_holder["p"].numpy()
-            result["cpu_baseline"], result["parity"] = cpu_baseline(
+            result["cpu_baseline"], result["parity"], ref_probs = cpu_baseline(
                 os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), x_host, probs, args.cpu_budget)
             if result["cpu_baseline"]["value"]:
                 result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
@@ -883,6 +1022,12 @@ def main():
             model.predict_on_counts(cnt, dep, decoded=True)
             diet.append(time.perf_counter() - t0)
         result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[1:])
+    if ranks.world == 1 and not args.shared_gpu and not args.half and args.extra_half:
+        # the precision `medaka inference` selects on a GPU by default, on the same line (reference prediction.py:164-168)
+        try:
+            result.setdefault("extra", {})["half"] = half_section(model, eng, x_dev, x_host, B, T, ranks, dev, args, ref_probs)
+        except Exception as exc:                      # the headline line must not depend on it
+            result.setdefault("extra", {})["half"] = {"error": f"{type(exc).__name__}: {exc}"}
     if ranks.world == 1 and not args.shared_gpu and args.extra_rl > 0:
         # BASELINE config 4b on the same line: the read-level rl_lstm384 architecture, timed by this same run
         import copy
@@ -891,10 +1036,11 @@ def main():
         del model, eng
         torch.cuda.empty_cache()
         try:
-            result["extra"] = {"rl384": main_rl(a2, emit=False)}
+            result.setdefault("extra", {})["rl384"] = main_rl(a2, emit=False)
         except Exception as exc:                      # the headline line must not depend on it
-            result["extra"] = {"rl384": {"error": f"{type(exc).__name__}: {exc}"}}
+            result.setdefault("extra", {})["rl384"] = {"error": f"{type(exc).__name__}: {exc}"}
     if ranks.rank == 0:
+        result["summary"] = summary_of(result)        # LAST key: whoever keeps only the tail of this line keeps the figures
         print(json.dumps(result), flush=True)
     ranks.close()
 

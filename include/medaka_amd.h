@@ -78,7 +78,7 @@ typedef struct {
 /* What the last forward did about splitting the scan (option "scan_split" below). */
 #define MDK_SPLIT_NOT_USED 0   /* shape not latency-bound, option off, or model outside the split path */
 #define MDK_SPLIT_CERTIFIED 1  /* ran as `chunks` chunks per window; every junction certified */
-#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-17 (half precision: 2^-10) at every margin tried:
+#define MDK_SPLIT_REJECTED 2   /* a junction differed by more than 2^-18 (half precision: 2^-10) at every margin tried:
                                   the call was answered by the sequential scan */
 #define MDK_SPLIT_DISABLED 3   /* an earlier call was rejected at the largest margin: sequential scans for a back-off of 64 .. 4096
                                   calls, then one more try (auto mode); after a failed AUDIT: for good */
@@ -182,9 +182,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   B * chunks windows of about T / chunks + 2 * margin columns.  The
  *                                                   states at every junction are compared on the device (both layers,
  *                                                   both directions, at the junction and margin / 2 columns past it);
- *                                                   if any differs by more than 2^-17 (2^-10 in half-precision mode)
- *                                                   the call is repeated with twice the margin -- kept for later
- *                                                   calls -- and beyond a margin of 512 as the sequential scan, which
+ *                                                   if any differs by more than 2^-18 (2^-10 in half-precision mode)
+ *                                                   the call is repeated with the next larger margin of the ladder 64, 96,
+ *                                                   128, 192, 256, 384, 512 -- kept for later calls -- and beyond a margin of 512 as the sequential scan, which
  *                                                   the model then stays on for a back-off of 64 calls (doubling up to
  *                                                   4096 per further rejection) before the split is tried again: the
  *                                                   rejection may have been that input's doing.  n >= 2 forces n chunks (no escalation:
@@ -192,6 +192,10 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   Bidirectional 2-layer models, T >= 8 * margin.  Results agree with
  *                                                   the sequential scan to ~1e-7 (not bit for bit) and depend, at that
  *                                                   level, on B and on the margin the model has escalated to.
+ *   "scan_split_adapt"     = 8 | 0 | n              the margin is LEARNED per model: after n certified calls in a row whose largest junction
+ *                                                   difference sat at the rounding-noise floor (a quarter of the threshold) the next call tries
+ *                                                   the next smaller margin of the ladder; a trial that is rejected is repeated at the margin
+ *                                                   that worked, and no shrink goes below a rejected margin again.  0: margins only grow.
  *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
  *                                                   it escalates to, and every "scan_split_audit_every"-th after that -- is
  *                                                   also run as the sequential scan and the two

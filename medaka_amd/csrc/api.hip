@@ -100,7 +100,12 @@ struct mdk_gru {
     // split scan (scan_split.hpp)
     int opt_scan_split = 1;                  // 0 off, 1 auto, n >= 2: n chunks per window whenever the shape allows it
     int opt_split_margin = 128;              // G: columns of warm-up on either side of a chunk (where the model starts)
-    int split_margin_cur = 0;                // margin in use: doubled (up to kSplitMarginMax) each time a certificate is rejected
+    int split_margin_cur = 0;                // margin in use (0: opt_split_margin): LEARNED per model -- one rung up the ladder 64 .. 512 on a
+                                             // rejected certificate, one rung down after `opt_split_adapt` certified calls at the noise floor
+    int opt_split_adapt = 8;                 // certified calls at the noise floor before a smaller margin is tried (0: never shrink)
+    int split_margin_floor = 0;              // no shrink below this: one rung above the largest margin a certificate was ever rejected at
+    int split_quiet = 0;                     // consecutive certified calls at the current margin with differences <= a quarter of the threshold
+    int split_trial_back = 0;                // != 0: the current margin is a shrink on trial; a rejection returns to this one
     bool split_disabled = false;             // a certificate failed at the largest margin (or an audit failed): sequential scans (auto mode)
     long split_retry_in = 0;                 // ... for this many calls; then one more try at the largest margin (0: for good -- failed audits)
     long split_backoff = 0;                  // the last back-off (doubles per rejection at the largest margin: 64 .. 4096 calls)
@@ -183,6 +188,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     m->layers.resize(L);
     // process-wide defaults of the split scan (the options of the same names override them per model)
     if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
+    if (const char *e = getenv("MDK_SCAN_SPLIT_ADAPT")) m->opt_split_adapt = std::max(atoi(e), 0);
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
         const int g = atoi(e);
         if (g >= 16 && g <= 4096 && g % 8 == 0) m->opt_split_margin = g;
@@ -410,16 +416,22 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_scan_split = value;
         m->split_disabled = false;           // setting the option re-arms a model that fell back
         m->split_retry_in = m->split_backoff = 0;
+        m->split_margin_floor = m->split_quiet = m->split_trial_back = 0;
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
     } else if (!strcmp(key, "scan_split_audit_every")) {
         if (value < 0) return fail(MDK_ERR_ARG, "scan_split_audit_every must be >= 0 (0 = only the first call of a margin)");
         m->opt_split_audit_every = value;
+    } else if (!strcmp(key, "scan_split_adapt")) {
+        if (value < 0) return fail(MDK_ERR_ARG, "scan_split_adapt must be >= 0 (certified calls at the noise floor before a smaller margin is tried; 0 = never)");
+        m->opt_split_adapt = value;
+        m->split_quiet = 0;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
         m->split_margin_cur = 0;
+        m->split_quiet = m->split_trial_back = 0;      // (what the certificates rejected so far stays learned: "scan_split" re-arms)
         m->split_disabled = false;
         m->split_retry_in = m->split_backoff = 0;
     } else {
@@ -1133,6 +1145,19 @@ extern "C" int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int m
     return MDK_OK;
 }
 
+// The margins a model can learn: a ladder instead of doublings (a set that needs 192 should not pay for 256: 19 % of all
+// columns against 25 %).  Margins outside the ladder (option "scan_split_margin") join it at the next rung.
+static const int kMarginLadder[] = {64, 96, 128, 192, 256, 384, 512};
+static int split_margin_up(int G) {
+    for (int r : kMarginLadder) if (r > G) return r;
+    return 2 * kSplitMarginMax;                      // above the ladder: the caller gives the model up
+}
+static int split_margin_down(int G, int floor_) {
+    int best = 0;
+    for (int r : kMarginLadder) if (r < G && r >= floor_) best = r;
+    return best;                                     // 0: nothing smaller is allowed
+}
+
 static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
     p.S = 1;
@@ -1244,6 +1269,21 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         if (keep) return MDK_OK;
         if (ok) {
             m->split_backoff = 0;
+            // The margin is the split's price (12.8 % of all columns at 128, 5.7 % at 64) and what it has to be is the MODEL's
+            // forgetting length: after `scan_split_adapt` certified calls in a row whose largest junction difference sat at the
+            // rounding-noise floor (a quarter of the threshold), the next call tries one rung less.  A trial that is rejected
+            // costs that one forward: the call is repeated at the margin that worked, and no shrink goes below it again.
+            if (m->split_trial_back) {
+                fprintf(stderr, "[medaka_amd] split scan: certified at a margin of %d columns (was %d): kept\n", sp.G, m->split_trial_back);
+                m->split_trial_back = 0;
+            }
+            const float quiet_thr = 0.25f * (m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps);
+            m->split_quiet = m->last_split.max_delta <= quiet_thr ? m->split_quiet + 1 : 0;
+            if (m->opt_scan_split == 1 && m->opt_split_adapt > 0 && m->split_quiet >= m->opt_split_adapt) {
+                const int down = split_margin_down(sp.G, m->split_margin_floor);
+                m->split_quiet = 0;
+                if (down) { m->split_trial_back = sp.G; m->split_margin_cur = down; }
+            }
             // Audit.  The certificate argues from the states at the junctions; the audit looks at what is delivered: the call is
             // ALSO run as the sequential scan on the device and the two (B, T, C) results are compared in full.  Audited are the
             // first certified call of a model (and the first at every margin / precision it moves to) and, as a STANDING check on
@@ -1302,8 +1342,18 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         // a rejection AT kSplitMarginMax: a very long or chaotic memory.  A forced chunk count is not second-guessed: the
         // call is answered sequentially.
         m->last_split.fallbacks++;
+        m->split_quiet = 0;
         if (m->opt_scan_split != 1) break;
-        const int next = 2 * sp.G;
+        m->split_margin_floor = std::max(m->split_margin_floor, split_margin_up(sp.G));     // never shrink to a rejected margin again
+        if (m->split_trial_back) {
+            // a shrink on trial did not certify: back to the margin that did (this call is repeated there)
+            fprintf(stderr, "[medaka_amd] split scan: a margin of %d columns does not certify (junction states differ by %.3g): back to %d\n",
+                    sp.G, m->last_split.max_delta, m->split_trial_back);
+            m->split_margin_cur = m->split_trial_back;
+            m->split_trial_back = 0;
+            continue;
+        }
+        const int next = split_margin_up(sp.G);
         if (next > kSplitMarginMax) {
             m->split_disabled = true;
             m->split_backoff = m->split_backoff ? std::min<long>(2 * m->split_backoff, 4096) : 64;
