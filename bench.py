@@ -617,6 +617,7 @@ def half_section(model, eng, x_dev, x_host, B, T, ranks, dev, args, ref_probs):
     from medaka_amd import dist
     from medaka_amd.torch_ext import Batch
     model.half()
+    eng = model.engine()                # (the parameters changed dtype: the model rebuilt its engine, from the fp16-rounded weights)
     eng.enable_timing(True)
     cols = B * T
     out = {}
