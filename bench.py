@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--procs-per-gpu", type=int, default=1,
                     help="K > 1: re-launch as K ranks of `--shared-gpu` on ONE GPU (medaka_amd.launch --procs-per-gpu K): the line's "
                          "`value` / `host_to_host` are the aggregates of the K processes, `n_gpus` counts the ranks")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="N > 1 smoke check: initialise the process group (RCCL, or gloo if RCCL is not usable), barrier, MAX / SUM over "
+                         "the ranks, print one JSON line with `barrier_backend` and `ranks_seen`, exit -- no model, no GPU work")
     ap.add_argument("--device-only", action="store_true",
                     help="profiling runs: only the device-resident timed steps (no host-to-host, CPU baseline, PCIe diet)")
     ap.add_argument("--stream-host", type=int, default=None, help="host path: 1 (default) = copies in time slabs under the recurrences / a split call's result under the second half of its last scan; 0 = one copy each side; 2 = a split call's result behind a side-stream head kernel (experiments)")
@@ -718,6 +721,16 @@ def main():
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.dry_ranks:
+        t0 = time.perf_counter()
+        ranks.barrier()
+        seen, slowest = ranks.ranks_seen(), ranks.max_over_ranks(time.perf_counter() - t0)
+        if ranks.rank == 0:
+            print(json.dumps({"dry_ranks": True, "n_gpus": ranks.world, "ranks_seen": seen, "barrier_backend": ranks.barrier_backend,
+                              "fallback_reason": ranks.fallback_reason, "barrier_s_max_over_ranks": slowest,
+                              "devices_visible_to_rank0": torch.cuda.device_count() if torch.cuda.is_available() else 0}), flush=True)
+        ranks.close()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback of the engine")
     dev = torch.device("cuda", 0 if args.shared_gpu else ranks.local_rank)
@@ -889,6 +902,7 @@ def main():
         "metric": "pileup columns/sec (consensus bi-GRU inference)",
         "value": value, "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
         "procs_per_gpu": ranks.world if args.shared_gpu else 1,
+        "barrier_backend": ranks.barrier_backend, "ranks_seen": ranks.ranks_seen(),
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else

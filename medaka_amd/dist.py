@@ -5,31 +5,93 @@ communication is a barrier before/after the timed region and a MAX all-reduce of
 time.  Backend "nccl" is RCCL on ROCm; the CPU tests run the same code over "gloo".
 """
 import os
+import sys
 import time
 
 
 class Ranks:
-    """Process-group context read from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE)."""
+    """Process-group context read from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE).
 
-    def __init__(self, backend=None):
+    The group only carries the barrier and the MAX / SUM of a few scalars around the timed region (the data path has no
+    collective), so the backend is a convenience, not a requirement: RCCL ("nccl") is tried where every rank has a GPU
+    of its own, and on ANY failure -- a rank without its device, an init error, a first all-reduce that raises or times
+    out -- ALL ranks fall back to gloo together (they agree through a TCPStore of their own, which needs no backend).
+    `backend` = "gloo" skips the attempt; `barrier_backend` says what is in use, `fallback_reason` why."""
+
+    def __init__(self, backend=None, nccl_timeout_s=90):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.backend = backend
+        self.fallback_reason = None
         self._pg = False
         if self.world > 1:
+            import datetime
             import torch
             import torch.distributed as dist
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
-            self.backend = backend
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            if dist.is_initialized():
+                self.backend = dist.get_backend()
+                return
+            # the ranks' own store: agreement on the backend must not depend on the backend
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 17, self.world, is_master=(self.rank == 0),
+                                  timeout=datetime.timedelta(seconds=300), wait_for_workers=True)
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-            if not dist.is_initialized():
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+                err = None
+                try:
+                    if not torch.cuda.is_available() or torch.cuda.device_count() <= self.local_rank:
+                        raise RuntimeError(f"rank {self.rank}: no HIP device {self.local_rank} (device_count = {torch.cuda.device_count()})")
+                    torch.cuda.set_device(self.local_rank)
+                except Exception as exc:               # noqa: BLE001 -- whatever it is, this rank cannot take part in RCCL
+                    err = f"{type(exc).__name__}: {exc}"
+                # phase A: does every rank have its device?  (nobody enters a collective that another rank cannot join)
+                store.set(f"mdk/dev/{self.rank}", err or "ok")
+                devs = [store.get(f"mdk/dev/{r}").decode() for r in range(self.world)]
+                bad = [d for d in devs if d != "ok"]
+                if not bad:
+                    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")      # a timeout raises instead of aborting the process
+                    try:
+                        dist.init_process_group(backend="nccl", store=dist.PrefixStore("mdk/nccl", store), rank=self.rank,
+                                                world_size=self.world, timeout=datetime.timedelta(seconds=nccl_timeout_s))
+                        t = torch.zeros(1, device=torch.device("cuda", self.local_rank))
+                        dist.all_reduce(t)                    # the communicator is only built here
+                        torch.cuda.synchronize()
+                    except Exception as exc:                  # noqa: BLE001
+                        err = f"{type(exc).__name__}: {str(exc)[:300]}"
+                    # phase B: did it work everywhere?
+                    store.set(f"mdk/nccl/{self.rank}", err or "ok")
+                    res = [store.get(f"mdk/nccl/{r}").decode() for r in range(self.world)]
+                    bad = [d for d in res if d != "ok"]
+                if bad:
+                    self.fallback_reason = bad[0]
+                    if dist.is_initialized():
+                        try:
+                            dist.destroy_process_group()
+                        except Exception:                      # noqa: BLE001
+                            pass
+                    if self.rank == 0:
+                        print(f"[medaka_amd.dist] RCCL process group not usable ({bad[0]}): barrier and reductions over gloo "
+                              "(the data path has no collective)", file=sys.stderr, flush=True)
+                    backend = "gloo"
+                else:
+                    self._pg = True
+            if backend == "gloo":
+                dist.init_process_group(backend="gloo", store=dist.PrefixStore("mdk/gloo", store), rank=self.rank, world_size=self.world,
+                                        timeout=datetime.timedelta(seconds=300))
                 self._pg = True
+            self.backend = backend
+            self._store = store
+
+    @property
+    def barrier_backend(self):
+        return self.backend if self.world > 1 else "none (one rank)"
+
+    def ranks_seen(self):
+        """How many ranks answer a SUM of ones: the world size, if the group works."""
+        return int(round(self.sum_over_ranks(1.0)))
 
     def _device(self):
         import torch

@@ -38,3 +38,45 @@ def test_two_rank_gloo_timing(tmp_path):
     assert r["world"] == 2 and r["calls"] == 4 and r["total"] == 11 and r["lo_hi"] == [0, 6]
     assert r["max"] >= 0.055          # slow rank: 3 * 0.02 s
     assert r["mine"] < r["max"]       # rank 0 is the fast one
+
+
+FALLBACK_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["MDK_ROOT"])
+from medaka_amd import dist
+ranks = dist.Ranks(backend="nccl")          # no GPU here: the RCCL attempt must fail on every rank and all of them move to gloo
+ranks.barrier()
+seen = ranks.ranks_seen()
+mx = ranks.max_over_ranks(10.0 + ranks.rank)
+if ranks.rank == 0:
+    print(json.dumps({"backend": ranks.barrier_backend, "reason": ranks.fallback_reason, "seen": seen, "max": mx}))
+ranks.close()
+"""
+
+
+def test_nccl_failure_falls_back_to_gloo_on_every_rank(tmp_path):
+    """`dist.Ranks` tries RCCL where it is asked to (or where there are GPUs); when that cannot work -- here: no device at
+    all -- every rank must end up in the SAME gloo group, with a working barrier / MAX / SUM (what bench.py --gpus N needs)."""
+    script = tmp_path / "worker.py"
+    script.write_text(FALLBACK_WORKER)
+    env = dict(os.environ, MDK_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "gloo" and r["seen"] == 2 and r["max"] == 11.0 and "no HIP device" in r["reason"], r
+    assert "RCCL process group not usable" in out.stderr
+
+
+def test_bench_dry_ranks_line():
+    """`bench.py --gpus N --dry-ranks`: process-group set-up, barrier and reductions only -- what a first 8-GPU launch can be
+    checked with before any model is built."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29553", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["dry_ranks"] and r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["barrier_backend"] == "gloo", r
