@@ -207,21 +207,17 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
- *   "stream_host"          = 1 | 0 | 2              mdk_gru_forward, sequential scan: copy x in / probabilities out in time
+ *   "stream_host"          = 1 | 0                  mdk_gru_forward, sequential scan: copy x in / probabilities out in time
  *                                                   slabs under the recurrences (0: one copy before, one after).  A split
  *                                                   call copies x in once (all of it is needed at once) and sends the
  *                                                   probabilities home in column chunks under the second half of the last
  *                                                   layer's scan when that half writes them itself ("final_head"; DMA
- *                                                   only: no kernel can run beside recurrences that hold every CU);
- *                                                   2 streams them behind a side-stream head kernel otherwise (experiments)
+ *                                                   only: no kernel can run beside recurrences that hold every CU),
+ *                                                   as one copy behind the forward otherwise
  *   "max_rows_per_pass"    = 0 (16 Mi) | n          column budget (B*T) of one pass over the workspace;
  *                                                   larger batches run as equal passes
- *   "ablate"               = timing-only ablation mask of the recurrence kernel (results invalid
- *                             unless 0; 64 = per-phase cycle counters, see mdk_gru_debug_read) */
+ * (the debug library adds "ablate": see the MDK_DEBUG_HOOKS block at the end of this header) */
 int mdk_gru_set_option(mdk_gru *m, const char *key, int value);
-
-/* Debug: phase cycle counters of the last recurrence launch under option "ablate" = 64. */
-int mdk_gru_debug_read(mdk_gru *m, unsigned long long *dst, int n);
 
 /* hipEvent timing of every kernel of the following forwards (adds a stream sync per forward). */
 int mdk_gru_enable_timing(mdk_gru *m, int on);
@@ -317,7 +313,6 @@ int mdk_rl_set_normalise(mdk_rl *m, int normalise);
  *                                                   behind resumable recurrence chunks (P >= 1024)
  *   "wide_wait_ms"         = 3000 | 0..60000        lstm_size 384: wall-clock budget of the host's retries after a
  *                                                   cluster time-out (0: the second time-out is the error)
- *   "wide_inject_timeout"  = n                      test hook: the next n tries find the time-out flag already raised
  *   "wide_write_through"   = 0 | 1                  lstm_size 384: always exchange h through write-through
  *                                                   granules, even when a cluster shares one XCD
  *   "wide_groups_per_cluster" = 0 (auto) | 1 | 2     lstm_size 384: 8-window groups interleaved per cluster
@@ -371,10 +366,20 @@ int mdk_device_synchronize(int device);
 
 /* MFMA fragment-layout / subnormal self-test run on the device (used by the gpu tests). */
 int mdk_selftest_mfma(int device, float *max_abs_err, int *subnormal_preserved);
-/* Test hook: occupy `blocks` CUs with a compute-bound loop of `iters` FMA pairs per lane (synchronous). */
+
+#ifdef MDK_DEBUG_HOOKS
+/* ---- test / profiling hooks: compiled ONLY into the debug library (medaka_amd/libmedaka_amd_debug.so, built with
+ * -DMDK_DEBUG_HOOKS by medaka_amd/build.py; `nm -D` of the release library shows none of them).  The debug library also
+ * accepts the options "ablate" (timing-only ablation masks of the recurrence kernel, wrong results) and
+ * "wide_inject_timeout" (the next n tries of the wide read-level forward find the time-out flag already raised), and the
+ * environment variables MDK_ABLATE and MDK_SPLIT_KEEP. */
+/* occupy `blocks` CUs with a compute-bound loop of `iters` FMA pairs per lane (synchronous) */
 int mdk_selftest_burn(int device, int blocks, int iters);
-/* Test hook: hold `blocks` CUs exclusively (one work-group with `lds_bytes` of LDS each) for `milliseconds`.  Synchronous. */
+/* hold `blocks` CUs exclusively (one work-group with `lds_bytes` of LDS each) for `milliseconds` (synchronous) */
 int mdk_selftest_hold(int device, int blocks, int milliseconds, int lds_bytes);
+/* per-phase cycle counters written by the ablate = 64 build of the recurrence kernel */
+int mdk_gru_debug_read(mdk_gru *m, unsigned long long *dst, int n);
+#endif
 
 const char *mdk_last_error(void);
 const char *mdk_version(void);

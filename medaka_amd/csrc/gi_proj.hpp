@@ -173,7 +173,11 @@ __global__ __launch_bounds__(512, MT <= 4 ? 4 : 2) void k_gi_gemm(
         // 2.73 -> 2.63 ms) and nothing at 1000 x 10000: the other work-group of the CU was already covering most of
         // that wait, and the kernel sits on L2 (10.5 TB/s of fragment reads), HBM (3.8 TB/s) and a 57 % busy,
         // power-limited matrix pipe at once.
-        half8 bh[2][NG], bl[2][NG];
+        // (four gate tiles in the fp32-parity split -- the LSTM projection -- and the K = 128 instantiation have no room for the
+        // second set inside 128 registers: with it hipcc spilled 67 / 79 / 3 VGPRs to scratch -- every reload a vmcnt(0) in front
+        // of the MFMAs.  ONE set there: the CU's other work-group covers the L2 round trip, as it did before round 3.)
+        constexpr int NSET = (!HP && (NG == 4 || KSTEPS == 4)) ? 1 : 2;
+        half8 bh[NSET][NG], bl[NSET][NG];
         auto load_b = [&](int ks, int set) {
 #pragma unroll
             for (int nt = 0; nt < NG; ++nt) {
@@ -198,17 +202,25 @@ __global__ __launch_bounds__(512, MT <= 4 ? 4 : 2) void k_gi_gemm(
             }
         };
         static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
-        load_b(0, 0);
+        if constexpr (NSET == 1) {
 #pragma unroll 1
-        for (int ks = 0; ks < KSTEPS; ks += 2) {
-            load_b(ks + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the requests to the end of the trip)
-            kstep(ks, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < KSTEPS) load_b(ks + 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(ks + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                load_b(ks, 0);
+                kstep(ks, 0);
+            }
+        } else {
+            load_b(0, 0);
+#pragma unroll 1
+            for (int ks = 0; ks < KSTEPS; ks += 2) {
+                load_b(ks + 1, NSET - 1);
+                __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the requests to the end of the trip)
+                kstep(ks, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < KSTEPS) load_b(ks + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ks + 1, NSET - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- epilogue: scale back, add folded bias, 256-byte runs per accumulator register

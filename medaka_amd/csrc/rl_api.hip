@@ -412,9 +412,11 @@ extern "C" int mdk_rl_set_option(mdk_rl *m, const char *key, int value) {
     } else if (!strcmp(key, "wide_wait_ms")) {
         if (value < 0 || value > 60000) return fail(MDK_ERR_ARG, "wide_wait_ms must be 0..60000");
         m->opt_wait_ms = value;
+#ifdef MDK_DEBUG_HOOKS
     } else if (!strcmp(key, "wide_inject_timeout")) {
         if (value < 0 || value > 1000) return fail(MDK_ERR_ARG, "wide_inject_timeout must be 0..1000");
         m->inject_timeouts = value;
+#endif
     } else if (!strcmp(key, "wide_write_through")) {
         m->opt_force_wt = value ? 1 : 0;
     } else if (!strcmp(key, "wide_poll_delay")) {
@@ -613,7 +615,7 @@ static int rl_forward_wide_once(mdk_rl *m, const unsigned char *x_dev, int B, in
 static int rl_forward_wide(mdk_rl *m, const unsigned char *x_dev, int B, int P, int Dp, int F,
                            float *probs_dev, hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
-    auto inject = [&]() -> int {          // test hook: raise the device flag before the try, as a lost forward would have
+    auto inject = [&]() -> int {          // test hook (debug builds: option "wide_inject_timeout"; never armed otherwise): raise the device flag before the try
         if (m->inject_timeouts <= 0 || !m->status) return MDK_OK;
         m->inject_timeouts--;
         const int one = 1;

@@ -65,7 +65,6 @@ ABI = {
     "mdk_gru_set_variant": (_i, [_vp, _i]),
     "mdk_gru_set_normalise": (_i, [_vp, _i]),
     "mdk_gru_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
-    "mdk_gru_debug_read": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "mdk_gru_enable_timing": (_i, [_vp, _i]),
     "mdk_gru_get_timing": (_i, [_vp, ctypes.POINTER(GruTiming)]),
     "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
@@ -101,11 +100,16 @@ ABI = {
     "mdk_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
     "mdk_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
     "mdk_device_synchronize": (_i, [_i]),
-    "mdk_selftest_burn": (_i, [_i, _i, _i]),
-    "mdk_selftest_hold": (_i, [_i, _i, _i, _i]),
     "mdk_selftest_mfma": (_i, [_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
     "mdk_last_error": (ctypes.c_char_p, []),
     "mdk_version": (ctypes.c_char_p, []),
+}
+
+# present only in the debug library (libmedaka_amd_debug.so, -DMDK_DEBUG_HOOKS): typed when found
+DEBUG_ABI = {
+    "mdk_selftest_burn": (_i, [_i, _i, _i]),
+    "mdk_selftest_hold": (_i, [_i, _i, _i, _i]),
+    "mdk_gru_debug_read": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }
 
 _lib = None
@@ -139,8 +143,18 @@ def load():
             raise ImportError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = restype
         fn.argtypes = argtypes
+    for name, (restype, argtypes) in DEBUG_ABI.items():       # the debug library's hooks, if this is one (MDK_LIB=.../libmedaka_amd_debug.so)
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def is_debug_library():
+    """True if the loaded library was built with -DMDK_DEBUG_HOOKS (test / profiling hooks present)."""
+    return hasattr(load(), "mdk_selftest_hold")
 
 
 def last_error():

@@ -93,3 +93,23 @@ def weight_set(gold, name):
     if name == "trained":
         return gold["weights_trained"]
     raise KeyError(name)
+
+
+@pytest.fixture
+def debug_hooks(request):
+    """Tests that need the test hooks of the DEBUG library (include/medaka_amd.h, MDK_DEBUG_HOOKS block: the release library
+    does not carry them).  Inside a process that has the debug library loaded: True.  Otherwise the test is re-executed in a
+    child process against medaka_amd/libmedaka_amd_debug.so, must pass there, and the fixture returns False (the caller
+    returns at once)."""
+    import subprocess
+    import sys
+    from medaka_amd import build, lib
+    if lib.is_debug_library():
+        return True
+    assert os.path.exists(build.LIB_DEBUG), f"{build.LIB_DEBUG} not built (python -c 'import __graft_entry__ as g; g.build()')"
+    env = dict(os.environ, MDK_LIB=build.LIB_DEBUG, MDK_SKIP_BUILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-p", "no:cacheprovider", request.node.nodeid],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return False

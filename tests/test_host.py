@@ -14,7 +14,9 @@ from medaka_amd.torch_ext import Batch
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "medaka_amd.h")).read()
-    declared = set(re.findall(r"\b(mdk_[a-z0-9_]+)\s*\(", header))
+    release, _, debug = header.partition("#ifdef MDK_DEBUG_HOOKS")
+    debug, _, tail = debug.partition("#endif")
+    declared = set(re.findall(r"\b(mdk_[a-z0-9_]+)\s*\(", release + tail))
     declared -= {"mdk_gru_timing"}
     assert len(declared) >= 20
     L = lib.load()
@@ -22,6 +24,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/medaka_amd.h but not exported"
         assert name in lib.ABI, f"{name} missing from the ctypes ABI table"
     assert set(lib.ABI) <= declared
+    # the test / profiling hooks live in the debug library only: the release library exports none of them
+    hooks = set(re.findall(r"\b(mdk_[a-z0-9_]+)\s*\(", debug))
+    assert hooks == set(lib.DEBUG_ABI) and len(hooks) == 3, hooks
+    if not lib.is_debug_library():
+        import subprocess
+        from medaka_amd import build
+        for path, want in ((build.LIB, False), (build.LIB_DEBUG, True)):
+            if os.path.exists(path):
+                syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+                for h in hooks:
+                    assert (f" {h}" in syms) == want, (path, h)
 
 
 def test_version_and_error_string():
