@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=None, help="MDK_VARIANT_* override (1 = exact fp32 kernels)")
     ap.add_argument("--tile", type=int, default=0, help="recurrence windows per work-group (0 auto, 4, 8, 16 = half precision only)")
     ap.add_argument("--half", action="store_true", help="model.half() path (reference GPU default)")
+    ap.add_argument("--parity-ref", default=None,
+                    help="path of a .npy with reference probabilities (n, T, 5) of the first n windows of this run's batch: `parity` is "
+                         "then this run's host-to-host result against it (how the fp32 line hands its CPU result to its --half child)")
     ap.add_argument("--extra-half", type=int, default=1,
                     help="1 (default): the fp32-parity line also carries `extra.half`, the same batch with model.half() -- what the "
                          "reference CLI selects on a GPU unless --full_precision (prediction.py:164-168); 0 = skip")
@@ -600,6 +603,7 @@ def summary_of(result):
     h = (result.get("extra") or {}).get("half") or {}
     if h:
         out["half"] = {"value": g(h, "value", scale=M), "ms_per_step": g(h, "ms_per_step", nd=3), "metric_8d": g(h, "metric_8d", "value", scale=M),
+                       "metric_8d_ms": g(h, "metric_8d", "ms_per_batch_median", nd=2),
                        "fed_loop": g(h, "fed_loop", "value", scale=M), "max_abs_dp": g(h, "parity", "max_abs_dp", nd=9),
                        "argmax_identical_columns": g(h, "parity", "argmax_identical_columns"), "columns_checked": g(h, "parity", "columns_checked"),
                        "split": g(h, "scan_split", "status"), "roofline_frac": g(h, "roofline", "frac", nd=4), "error": h.get("error")}
@@ -610,78 +614,45 @@ def summary_of(result):
     return out
 
 
-def half_section(model, eng, x_dev, x_host, B, T, ranks, dev, args, ref_probs):
+def half_section(args, ref_probs):
     """What `medaka inference` runs on a GPU BY DEFAULT (reference prediction.py:164-168: model.half() unless
-    --full_precision) on the same batch, in the same process: device-resident rate, host-to-host, the fed
-    loop, the split certificate, the dominant kernel against the fp16 peak, and parity of the full batch against the
-    fp32 PyTorch-CPU result of this run's cpu_baseline."""
+    --full_precision): this same benchmark with --half in a child process of its own (a fresh engine, the same code path as
+    the line above; this process is idle meanwhile), reduced to its figures; parity of ITS host-to-host result against the
+    fp32 PyTorch-CPU result of this run's cpu_baseline (handed over through a temporary file)."""
+    import subprocess
+    import tempfile
     import numpy as np
-    import torch
-    from medaka_amd import dist
-    from medaka_amd.torch_ext import Batch
-    model.half()
-    eng = model.engine()                # (the parameters changed dtype: the model rebuilt its engine, from the fp16-rounded weights)
-    eng.enable_timing(True)
-    cols = B * T
-    out = {}
-
-    def step():
-        with torch.inference_mode():
-            out["y"] = model.forward(x_dev)
-    step(); torch.cuda.synchronize(dev)               # first call at this precision: audited against the sequential scan
-    first = eng.split()
-    rec0, rec1, gi, head, total, flags = [], [], [], [], [], [0]
-
-    def step_timed():
-        step()
-        t = eng.timing()
-        rec0.append(t["rec_ms"][0]); rec1.append(t["rec_ms"][1] if len(t["rec_ms"]) > 1 else 0.0)
-        gi.append(sum(t["gi_ms"])); head.append(t["head_ms"]); total.append(t["total_ms"]); flags[0] = t["fused_layers"]
-    n = max(5, args.steps)
-    elapsed, _ = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev), steps=n, warmup=2)
-    split = eng.split()
-    res = {"what": "model.half() -- the reference CLI's GPU default (prediction.py:164-168) -- same batch, same process: fp16 operands, "
-                   "fp32 accumulate, single product (k_rec_fused<HP>)",
-           "value": ranks.world * cols * n / elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * elapsed / n, "steps": n, "warmup": 2,
-           "scan_split": {k: split[k] for k in ("chunks", "columns", "margin", "status", "max_delta", "fallbacks")},
-           "first_call_audit_max_dp": first["audit_max_dp"], "first_call_audited": first["audited"]}
-    kernels, step_level = kernel_table((rec0[-n:], rec1[-n:], gi[-n:], head[-n:], total[-n:]), flags[0], split, B, T, True)
-    dom = max(kernels, key=lambda e: e["ms_per_step"])
-    res["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["algorithmic_tflops"], "peak": PEAK_F16_DENSE_TFLOPS,
-                       "unit": "TFLOP/s", "frac": dom["algorithmic_tflops"] / PEAK_F16_DENSE_TFLOPS, "frac_issued": dom["frac_issued_of_fp16_peak"],
-                       "avg_launch_ms": dom["ms_per_step"], "launches_timed": n,
-                       "peak_note": "fp16 dense MFMA peak, undivided: half precision issues one fp16 MAC per algorithmic MAC",
-                       "kernels": kernels, "step": step_level}
-    # host tensor in -> host tensor out, as the fp32 line measures it
-    eng.enable_timing(False)
-    xb = Batch(counts_matrix=torch.from_numpy(x_host).pin_memory())
-    h2h = []
-    t_settle = time.perf_counter()
-    while len(h2h) < 8 or time.perf_counter() - t_settle < 0.6:
-        t0 = time.perf_counter(); p = model.predict_on_batch(xb); h2h.append(time.perf_counter() - t0)
-    first_calls = [round(1e3 * t, 3) for t in h2h[:6]]
-    timed = []
-    for _ in range(max(5, args.host_reps)):
-        t0 = time.perf_counter(); p = model.predict_on_batch(xb); timed.append(time.perf_counter() - t0)
-    med = statistics.median(timed)
-    res["metric_8d"] = {"value": ranks.world * cols / med, "unit": "pileup columns/s", "ms_per_batch_median": 1e3 * med,
-                        "timed_batches": len(timed), "first_calls_ms": first_calls}
-    probs = p.numpy()
-    if ref_probs is not None:
-        k = ref_probs.shape[0]
-        res["parity"] = {"max_abs_dp": float(np.abs(probs[:k] - ref_probs).max()),
-                         "argmax_identical_columns": int((probs[:k].argmax(-1) == ref_probs.argmax(-1)).sum()),
-                         "columns_checked": int(k * T), "tolerance": 1e-4,
-                         "against": "fp32 PyTorch-CPU result of cpu_baseline (the same windows), split scan on"}
-    if args.loop_batches > 2 and ranks.world == 1:
-        from medaka_amd import torch_ext
-        windows = loop_windows(T, args.depth, 4321)
-        fast = lambda data: torch_ext.Batch.collate(data)
-        fed_loop(model, windows, B, 3, fast, warm=1)
-        fl = fed_loop(model, windows, B, args.loop_batches, fast)
-        res["fed_loop"] = {k: fl[k] for k in ("value", "ms_per_batch", "predict_ms_median", "collate_ms_median", "timed_batches")}
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.abspath(__file__), "--half", "--cpu-budget", "0", "--extra-rl", "0", "--extra-half", "0",
+               "--steps", str(max(5, args.steps)), "--warmup", str(max(2, args.warmup)), "--batch", str(args.batch),
+               "--chunk-len", str(args.chunk_len), "--depth", str(args.depth), "--loop-batches", str(args.loop_batches)]
+        if ref_probs is not None:
+            ref = os.path.join(tmp, "ref.npy")
+            np.save(ref, ref_probs)
+            cmd += ["--parity-ref", ref]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench --half failed (rc {r.returncode}): {r.stderr[-400:]}")
+    h = json.loads(lines[-1])
+    roof = h.get("roofline") or {}
+    res = {"what": "model.half() -- the reference CLI's GPU default (prediction.py:164-168): `bench.py --half` on the same batch in a child "
+                   "process, same definitions as the line above (fp16 operands, fp32 accumulate, one product: k_rec_fused<HP>)",
+           "value": h["value"], "unit": h["unit"], "ms_per_step": h["ms_per_step"], "steps": h["steps"], "warmup": h["warmup"], "dtype": h["dtype"],
+           "scan_split": {k: h["scan_split"].get(k) for k in ("chunks", "columns", "margin", "status", "max_delta", "fallbacks",
+                                                              "first_call_audited", "first_call_audit_max_dp")},
+           "metric_8d": {k: h["host_to_host"].get(k) for k in ("value", "unit", "ms_per_batch_median", "timed_batches", "first_calls_ms",
+                                                               "frac_of_device_resident", "one_copy_each_way_ms_per_batch")},
+           "sequential_scan": h.get("sequential_scan"), "value_at_learned_margin": h.get("value_at_learned_margin"),
+           "fed_loop": ({"value": h["fed_loop"]["value"], **{k: h["fed_loop"]["engine_collate"].get(k) for k in
+                                                             ("ms_per_batch", "predict_ms_median", "collate_ms_median", "timed_batches")}}
+                        if h.get("fed_loop") else None),
+           "pcie_diet_columns_per_s": h.get("pcie_diet_columns_per_s"),
+           "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_issued", "avg_launch_ms",
+                                                 "launches_timed", "peak_note", "kernels", "step")},
+           "parity": h.get("parity")}
     log(f"half precision: {res['value'] / 1e6:.1f} M columns/s device-resident ({res['ms_per_step']:.2f} ms), "
-        f"{res['metric_8d']['value'] / 1e6:.1f} M host-to-host, split {split['status']}, parity {res.get('parity', {}).get('max_abs_dp')}")
+        f"{res['metric_8d']['value'] / 1e6:.1f} M host-to-host, split {res['scan_split']['status']}, parity {(res.get('parity') or {}).get('max_abs_dp')}")
     return res
 
 
@@ -1024,6 +995,14 @@ def main():
                 os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), x_host, probs, args.cpu_budget)
             if result["cpu_baseline"]["value"]:
                 result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        if args.parity_ref:
+            ref = np.load(args.parity_ref)
+            got = out_holder["p"].numpy()[:ref.shape[0]]
+            result["parity"] = {"max_abs_dp": float(np.abs(got - ref).max()),
+                                "argmax_identical_columns": int((got.argmax(-1) == ref.argmax(-1)).sum()),
+                                "argmax_identical": bool((got.argmax(-1) == ref.argmax(-1)).all()),
+                                "columns_checked": int(ref.shape[0] * T), "tolerance": 1e-4,
+                                "against": "the reference probabilities handed in with --parity-ref (the fp32 line's PyTorch-CPU result)"}
         if args.loop_batches > 2 and ranks.world == 1:
             result["fed_loop"] = loop_report(model, B, T, args.depth, 4321, args.loop_batches,
                                              result["host_to_host"]["value"])
@@ -1040,7 +1019,7 @@ def main():
     if ranks.world == 1 and not args.shared_gpu and not args.half and args.extra_half:
         # the precision `medaka inference` selects on a GPU by default, on the same line (reference prediction.py:164-168)
         try:
-            result.setdefault("extra", {})["half"] = half_section(model, eng, x_dev, x_host, B, T, ranks, dev, args, ref_probs)
+            result.setdefault("extra", {})["half"] = half_section(args, ref_probs)
         except Exception as exc:                      # the headline line must not depend on it
             result.setdefault("extra", {})["half"] = {"error": f"{type(exc).__name__}: {exc}"}
     if ranks.world == 1 and not args.shared_gpu and args.extra_rl > 0:

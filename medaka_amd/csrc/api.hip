@@ -124,11 +124,14 @@ struct mdk_gru {
     // early hand-over of the next batch (mdk_gru_stage_input): its host -> device copy runs on `stage_stream` while the
     // caller's thread is still inside the forward of the previous one
     struct StageSlot { unsigned long long token = 0; bool busy = false; float *dev = nullptr; size_t cap = 0; int B = 0, T = 0; hipEvent_t ready = nullptr; };
-    StageSlot stage[12];     // the reference's loader runs up to 8 batches ahead of the model (prediction.py:229, batch_cache_size)
+    StageSlot stage[10];     // the reference's loader runs up to 8 batches ahead of the model (prediction.py:229, batch_cache_size): those, the
+                             // one the forward is reading and the one being filled; buffers are allocated on first use, sized to the batch
     unsigned long long stage_next_token = 1;
     hipStream_t stage_stream = nullptr;
     std::mutex stage_mu;
     long staged_used = 0;
+    int stage_unredeemed = 0;                // slots overwritten in a row whose token nobody had redeemed
+    int stage_pause = 0;                     // > 0: the next this many hand-overs are skipped (nobody was redeeming them)
     // standing audit: every `opt_split_audit_every`-th certified call is ALSO run as the sequential scan (run_forward)
     int opt_split_audit_every = 256;
     long split_calls_since_audit = 0;
@@ -1574,24 +1577,41 @@ extern "C" int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T
     *token = 0;
     if (B <= 0 || T <= 0 || !x_host) return fail(MDK_ERR_ARG, "bad batch B=%d T=%d", B, T);
     HIP_TRY(hipSetDevice(m->device));
-    std::lock_guard<std::mutex> lock(m->stage_mu);
-    if (!m->stage_stream) HIP_TRY(hipStreamCreateWithFlags(&m->stage_stream, hipStreamNonBlocking));
-    // a free slot, else the one staged longest ago (a token nobody redeemed in time simply stops being valid); never the
-    // slot a forward is reading
+    // Pick a slot under the lock, fill it outside: the (re)allocation of its buffer and the wait for an unredeemed copy
+    // synchronise the device, and mdk_gru_forward_staged -- the caller's main thread -- needs the same lock.
     mdk_gru::StageSlot *sl = nullptr;
-    for (auto &c : m->stage)
-        if (!c.busy && (!sl || c.token < sl->token)) sl = &c;
-    if (!sl) return fail(MDK_ERR_ARG, "no staging slot free");
-    const size_t n = (size_t)B * T * m->desc.num_features;
-    if (sl->ready) HIP_TRY(hipEventSynchronize(sl->ready));        // (an unredeemed copy into this slot may still be running)
-    if (n > sl->cap) {
-        free_dev(sl->dev); sl->dev = nullptr; sl->cap = 0;
-        HIP_TRY(hipMalloc((void **)&sl->dev, n * sizeof(float)));
-        sl->cap = n;
+    {
+        std::lock_guard<std::mutex> lock(m->stage_mu);
+        if (!m->stage_stream) HIP_TRY(hipStreamCreateWithFlags(&m->stage_stream, hipStreamNonBlocking));
+        // nobody is redeeming the tokens (another model took the batches, or the caller uses the counts / decoded entries):
+        // every copy would cross PCIe for nothing -- pause, and look again later
+        if (m->stage_pause > 0) { m->stage_pause--; return MDK_OK; }
+        // a free slot, else the one staged longest ago (a token nobody redeemed in time simply stops being valid); never the
+        // slot a forward is reading or another stager is filling
+        for (auto &c : m->stage)
+            if (!c.busy && (!sl || c.token < sl->token)) sl = &c;
+        if (!sl) return fail(MDK_ERR_ARG, "no staging slot free");
+        if (sl->token != 0 && ++m->stage_unredeemed >= 4) { m->stage_unredeemed = 0; m->stage_pause = 64; }
+        sl->busy = true;
+        sl->token = 0;
     }
-    if (!sl->ready) HIP_TRY(hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(sl->dev, x_host, n * sizeof(float), hipMemcpyHostToDevice, m->stage_stream));
-    HIP_TRY(hipEventRecord(sl->ready, m->stage_stream));
+    const size_t n = (size_t)B * T * m->desc.num_features;
+    int rc = MDK_OK;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == MDK_OK) rc = fail(e == hipErrorOutOfMemory ? MDK_ERR_OOM : MDK_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (sl->ready) hip_ok(hipEventSynchronize(sl->ready), "hipEventSynchronize");        // (an unredeemed copy into this slot may still be running)
+    if (rc == MDK_OK && n > sl->cap) {
+        free_dev(sl->dev); sl->dev = nullptr; sl->cap = 0;
+        if (hip_ok(hipMalloc((void **)&sl->dev, n * sizeof(float)), "hipMalloc")) sl->cap = n;
+    }
+    if (rc == MDK_OK && !sl->ready) hip_ok(hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming), "hipEventCreate");
+    if (rc == MDK_OK) hip_ok(hipMemcpyAsync(sl->dev, x_host, n * sizeof(float), hipMemcpyHostToDevice, m->stage_stream), "hipMemcpyAsync");
+    if (rc == MDK_OK) hip_ok(hipEventRecord(sl->ready, m->stage_stream), "hipEventRecord");
+    std::lock_guard<std::mutex> lock(m->stage_mu);
+    sl->busy = false;
+    if (rc != MDK_OK) return rc;
     sl->B = B; sl->T = T;
     sl->token = m->stage_next_token++;
     *token = sl->token;
@@ -1606,7 +1626,7 @@ extern "C" int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int 
     {
         std::lock_guard<std::mutex> lock(m->stage_mu);
         for (auto &c : m->stage)
-            if (c.token == token && c.B == B && c.T == T && !c.busy) { sl = &c; c.busy = true; c.token = 0; }
+            if (c.token == token && c.B == B && c.T == T && !c.busy) { sl = &c; c.busy = true; c.token = 0; m->stage_unredeemed = 0; }
     }
     if (!sl) return fail(MDK_ERR_ARG, "unknown or expired staging token (use mdk_gru_forward)");
     const size_t np = (size_t)B * T * m->desc.num_classes;

@@ -95,6 +95,8 @@ class GruEngine:
 
     def __init__(self, state, num_features=10, gru_size=128, n_layers=2, bidirectional=True,
                  num_classes=5, normalise=True, device=0):
+        import threading
+        self._stage_lock = threading.Lock()       # stage_input (Batcher thread) against close()
         self._h = ctypes.c_void_p()
         L = _lib.load()
         keys = state_keys(n_layers, bidirectional)
@@ -208,9 +210,13 @@ class GruEngine:
         return cls, pmax
 
     def stage_input(self, x_ptr, B, T):
-        """Start the host -> device copy of a batch now (`mdk_gru_stage_input`); returns the token `forward_staged` takes."""
+        """Start the host -> device copy of a batch now (`mdk_gru_stage_input`); returns the token `forward_staged` takes
+        (0: not staged).  Called from the loader's Batcher thread: serialised against `close()`."""
         tok = ctypes.c_ulonglong(0)
-        _lib.check(_lib.load().mdk_gru_stage_input(self._h, x_ptr, int(B), int(T), ctypes.byref(tok)), "mdk_gru_stage_input")
+        with self._stage_lock:
+            if not self._h:
+                return 0
+            _lib.check(_lib.load().mdk_gru_stage_input(self._h, x_ptr, int(B), int(T), ctypes.byref(tok)), "mdk_gru_stage_input")
         return tok.value
 
     def forward_staged(self, token, B, T, out_ptr):
@@ -231,9 +237,14 @@ class GruEngine:
                        "mdk_gru_forward_dev")
 
     def close(self):
-        if self._h:
-            _lib.load().mdk_gru_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        # a Batcher thread may be inside stage_input: no hand-over targets this engine any more, and the handle is only
+        # destroyed once that call has returned
+        from medaka_amd import torch_ext as _te
+        _te.forget_stage_target(self)
+        with self._stage_lock:
+            h, self._h = self._h, ctypes.c_void_p()
+        if h:
+            _lib.load().mdk_gru_destroy(h)
 
     def __del__(self):
         try:

@@ -204,7 +204,8 @@ class GRUModel(CountsMatrixModel):
             # host tensor in -> host tensor out through the engine's own staging
             # (models.py:309-312 does .to(device) ... .cpu())
             eng = self.engine()
-            staged = getattr(x, "_mdk_stage", None)           # (engine, token) left by the engine's Batch.collate
+            from medaka_amd import torch_ext as _te
+            staged = _te.staged_is_current(x)                 # (engine, token) left by the engine's Batch.collate, if x is untouched since
             x = x.detach().to(torch.float32).contiguous()
             if x.dim() != 3 or x.shape[2] != self.num_features:
                 raise ValueError(f"expected (B, T, {self.num_features}) input, got {tuple(x.shape)}")

@@ -48,6 +48,13 @@ def set_stage_target(engine):
     _stage_target = weakref.ref(engine) if engine is not None else None
 
 
+def forget_stage_target(engine):
+    """`engine` is being closed: no further batch is handed to it."""
+    global _stage_target
+    if _stage_target is not None and _stage_target() is engine:
+        _stage_target = None
+
+
 def _stage(out):
     if _stage_target is None or os.environ.get("MEDAKA_AMD_STAGE", "1") == "0" or not out.is_pinned():
         return
@@ -55,9 +62,29 @@ def _stage(out):
     if eng is None or out.dim() != 3 or out.shape[2] != eng.num_features:
         return
     try:
-        out._mdk_stage = (eng, eng.stage_input(out.data_ptr(), out.shape[0], out.shape[1]))
+        tok = eng.stage_input(out.data_ptr(), out.shape[0], out.shape[1])
+        if tok:
+            # what was copied: this tensor, these bytes.  `predict_on_batch` redeems the token only if the tensor is still the
+            # one that was handed over -- same storage, same shape, no in-place edit since (staged_is_current)
+            out._mdk_stage = (eng, tok, out._version, out.data_ptr(), tuple(out.shape))
     except Exception:        # staging is an optimisation: the ordinary path answers
         pass
+
+
+def staged_is_current(x):
+    """The (engine, token) a tensor carries from `_stage`, if the device copy still is the tensor's content: nothing wrote to
+    it in place since the hand-over (torch's version counter), same storage, same shape.  None otherwise -- the ordinary
+    host path then copies what the tensor holds NOW."""
+    st = getattr(x, "_mdk_stage", None)
+    if st is None:
+        return None
+    try:
+        eng, tok, ver, ptr, shape = st
+        if x._version == ver and x.data_ptr() == ptr and tuple(x.shape) == shape:
+            return eng, tok
+    except Exception:
+        pass
+    return None
 
 
 def stack_counts(feats, threads=None):
