@@ -283,3 +283,19 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
           f"({ratio:.2f} x); host-to-host {r2['host_to_host']['value'] / 1e6:.1f} M against {r1['host_to_host']['value'] / 1e6:.1f} M")
     assert 0.6 <= ratio <= 1.6, ratio
     assert r2["host_to_host"]["value"] > 0 and r2["roofline"]["kernels"]
+
+
+def test_validate_tool_on_a_state_dict(gold, tmp_path):
+    """`python -m medaka_amd.validate weights.npz` end to end on the device (small shape): both precisions, the margin
+    table, the learned margin, every input structure against PyTorch-CPU."""
+    from medaka_amd import validate
+    rep = validate.main([os.path.join(GOLD, "weights_trained.npz"), "--batch", "24", "--chunk-len", "6000", "--sample-windows", "2",
+                         "--json", str(tmp_path / "v.json")])
+    for prec, tol in (("fp32", 2e-5), ("half", 4e-4)):
+        r = rep[prec]
+        assert r["margin_table_iid"][128]["status"] == "certified" and r["smallest_certified_margin"] in (64, 96, 128), r["margin_table_iid"]
+        assert r["learned"]["status"] == "certified" and r["learned"]["settled_at"] in (64, 96, 128)
+        assert r["device_resident"]["columns_per_s"] > r["sequential_scan"]["columns_per_s"] > 0 and r["host_to_host"]["columns_per_s"] > 0
+        for kind, k in r["inputs"].items():
+            assert k["status"] in ("certified", "rejected", "disabled", "not used")
+            assert k["max_abs_dp_vs_cpu"] <= tol and k["argmax_identical"] >= 0.999 * k["columns_checked"], (prec, kind, k)

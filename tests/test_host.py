@@ -455,6 +455,35 @@ def test_install_swaps_the_model_inside_the_reference_load_model(name, tmp_path,
     assert model.to_dict() == ref.to_dict()
 
 
+def test_validate_plan_only_on_a_state_dict_and_on_a_reference_archive(tmp_path, capsys):
+    """`python -m medaka_amd.validate <model> --plan-only`: the device-free half of the one-command
+    check for real model archives -- an .npz state dict, and a .tar.gz through the UNMODIFIED reference's
+    `ModelStoreTGZ.load_model` (the flow a real archive takes)."""
+    import functools
+    import pickle
+    import tarfile
+    from medaka_amd import validate
+    rep = validate.main([os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), "--plan-only", "--batch", "100"])
+    assert rep["model"]["class"] == "GRUModel" and rep["model"]["engine_covers_it"]
+    assert rep["model"]["split_plan_at_margin_128"] == {"batch": 100, "columns": 10000, "chunks": 10, "virtual_columns": 1264, "margin": 128}
+    ref_shim.install()
+    import medaka.architectures as arch
+    import medaka.models as ref_models
+    ref = arch.GRUModel(num_features=10, gru_size=128, n_layers=2, bidirectional=True)
+    top = tmp_path / "model"
+    top.mkdir()
+    torch.save(ref.state_dict(), top / "weights.pt")
+    with open(top / "meta.pkl", "wb") as fh:
+        pickle.dump({"model_function": functools.partial(ref_models.model_from_dict, ref.to_dict())}, fh)
+    tgz = tmp_path / "toy_model_pt.tar.gz"
+    with tarfile.open(tgz, "w:gz") as tar:
+        tar.add(top, arcname="model")
+    rep = validate.main([str(tgz), "--plan-only", "--json", str(tmp_path / "r.json")])
+    assert rep["model"]["source"] == "ModelStoreTGZ.load_model" and rep["model"]["class"] == "GRUModel" and rep["model"]["engine_covers_it"]
+    assert json.load(open(tmp_path / "r.json"))["plan_only"]
+    capsys.readouterr()
+
+
 def _build_c_host(tmp_path):
     import subprocess
     from medaka_amd import build as _build
