@@ -436,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void k_rec_fused(
             // the W_ih fragments want to stay in -- 6.40 -> 6.29 ms per forward, profiles/r5_experiments/README.md)
             for (int q = 0; q < 2; ++q) buf_store_float<2>(hprev[q], orsrc, ovoff + q * 256, so_prev);
             // the piece requested two steps ago has arrived by now: split it and put it into the image (under the MFMAs)
+            // (two steps of flight are enough: three or four change nothing -- profiles/r5_experiments/README.md)
             if (j >= 2 && (j - 2) % kIssue == 0 && (j - 2) / kIssue < NPIECE) piece_store((j - 2) / kIssue, pc[(j - 2) / kIssue]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
