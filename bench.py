@@ -456,6 +456,34 @@ def rl_traffic(model, B, P, D):
         return None
 
 
+def rl_kernel_entries(wide, B, P, D, front_ms, total_ms, half, front_tflops):
+    """The read-level forward per kernel family: the front end (hipEvents of its own) and what follows it -- the LSTM stack
+    with its projections and the head (device total minus the front end; the per-kernel split of that remainder is in the
+    committed trace, profiles/r5_rl384_kernel_stats.csv / r5_rl128_kernel_stats.csv)."""
+    rest = max(total_ms - front_ms, 1e-6)
+    cols = float(B) * P
+    if wide:      # lstm 384, four uni-directional layers (reverse, forward, reverse, forward), layer 0 fed by the 128 CNN channels
+        mac = (128 + 384) * 1536 + 3 * (384 + 384) * 1536
+        layers, what = 4, ("4 x k_lstm_wide (LSTM 384 on clusters of 12 CUs, h exchanged through L2; B / 8 clusters: 13 x 12 = 156 CUs at "
+                           "batch 100) with k_gemm_rows (next layer's projection) beside it on a side stream, then k_linear_softmax")
+    else:         # lstm 128, two bi-directional layers
+        mac = 2 * (128 + 128) * 512 + 2 * (256 + 128) * 512
+        layers, what = 2, "per layer k_gi_gemm<NG = 4> (projection) + k_rec_mfma<CELL = 1> (LSTM 128 recurrence, both directions), then k_head_tiled"
+    issue = 1 if half else 4
+    tf = 2.0 * mac * cols / (rest * 1e-3) / 1e12
+    return [
+        {"kernel": "k_rl_front", "ms_per_step": front_ms, "algorithmic_tflops": front_tflops,
+         "frac_algorithmic_of_fp16_peak": front_tflops / PEAK_F16_DENSE_TFLOPS,
+         "frac_issued_of_fp16_peak": front_tflops * (1 if half else 3) / PEAK_F16_DENSE_TFLOPS},
+        {"kernel": "LSTM stack + head: " + what, "ms_per_step": rest, "layers": layers,
+         "us_per_scan_step_and_layer": 1e3 * rest / (layers * P),
+         "algorithmic_mac_per_column": mac, "algorithmic_tflops": tf, "frac_algorithmic_of_fp16_peak": tf / PEAK_F16_DENSE_TFLOPS,
+         "frac_issued_of_fp16_peak": tf * issue / PEAK_F16_DENSE_TFLOPS,
+         "bound": "the latency of " + str(layers * P) + " dependent steps (a step cannot be shortened and a split scan does not help here: "
+                  "profiles/r4_experiments/README.md), not the matrix pipe"},
+    ]
+
+
 def main_rl(args, emit=True):
     """BASELINE config 4b: the read-level model (reference LatentSpaceLSTM) over uint8 read matrices, one GPU
     per rank, input resident in HBM.  rl384 = the bundled rl_lstm384 architecture (lstm 384, 4 x uni-directional,
@@ -528,6 +556,7 @@ def main_rl(args, emit=True):
                              "on all SIMDs sustains 0.81 (4 s) to 0.64-0.67 (25 s) of the nominal rate on this chip (profiles/probes/mfma_burn*.hip), "
                              "the kernel's matrix pipe is 81 % busy at a power-limited 1.69 GHz (profiles/r3_experiments/front/)",
                      "kernel_ms_per_step": {"front": statistics.mean(front), "device_total": statistics.mean(total)},
+                     "kernels": rl_kernel_entries(wide, B, P, D, statistics.mean(front), statistics.mean(total), args.half, achieved),
                      "wide_retries": eng.timing()["wide_retries"]},
     }
     # host tensor in -> host tensor out, as the prediction loop calls it
