@@ -431,10 +431,10 @@ def test_split_streamed_host_path_agrees_bitwise(gold, B, T):
     assert e.forward_staged(tok, B, T, pin_p.array.ctypes.data) and np.array_equal(pin_p.array, want)
     assert e.timing()["host_streamed"] & 4
     assert not e.forward_staged(tok, B, T, pin_p.array.ctypes.data)           # a token is good for one forward
-    n_slots = 12 if B * T <= 400000 else 3                                      # (keep the big shapes cheap)
-    toks = [e.stage_input(pin_x.array.ctypes.data, B, T) for _ in range(n_slots + (1 if n_slots == 12 else 0))]
-    if n_slots == 12:
-        assert not e.forward_staged(toks[0], B, T, pin_p.array.ctypes.data)    # twelve slots: the thirteenth pushes the first out
+    n_slots = 10 if B * T <= 400000 else 3                                      # (keep the big shapes cheap)
+    toks = [e.stage_input(pin_x.array.ctypes.data, B, T) for _ in range(n_slots + (1 if n_slots == 10 else 0))]
+    if n_slots == 10:
+        assert not e.forward_staged(toks[0], B, T, pin_p.array.ctypes.data)    # ten slots: the eleventh pushes the first out
         toks = toks[1:]
     for t in toks:
         pin_p.array[...] = -1.0
