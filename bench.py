@@ -365,7 +365,7 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
                   "frac_issued_of_fp16_peak": issued / ms / 1e9 / PEAK_F16_DENSE_TFLOPS,
                   "hbm_algorithmic_gb": hbm_bytes / 1e9, "hbm_gb_per_s": hbm_bytes / ms / 1e6, "note": note})
     entry("k_rec_mfma<XIN> (layer 0: recurrence + fused K=10 projection; k_pack_x inside its span)", rec0, 98304 + 7680,
-          wg_cols * 8 * (12 * prod + 3 * prod), vcols * (1024 + 1024 / (4 * nq)) + vcols * (40 + 1024 / (4 * nq)),
+          wg_cols * 8 * (12 * prod + 3 * prod), vcols * (1024 + 512 / (4 * nq)) + vcols * (40 + 512 / (4 * nq)),
           "8 waves x (24 + 6) MFMAs per work-group and step")
     if fused1:
         entry("k_rec_fused (layer 1: K=256 projection + recurrence" + (" + classifier Linear" if fused_head else "") +

@@ -316,7 +316,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
         if (l > 0 && (rc = upload(&Ld.wih_frag, wih_frag))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_rec, inv_rec))) return bail(rc);
         if ((rc = upload(&Ld.inv_scale_gi, inv_gi))) return bail(rc);
-        if (l == 0 && K + 1 <= 32) {
+        if (l == 0 && K + 1 <= 8 * (kXfragLanes / 16)) {      // features + the bias row inside the packed block's k-slots
             // fused layer-0 projection: one sx for all directions (the packed x is shared),
             // per-direction W_ih scale swx = S_d / sx
             float sx = 16.0f;
@@ -762,7 +762,7 @@ void Pass::launch_head(const float *src, hipStream_t st, int t0, int nt) {
 
 void Pass::pack_cols(const LayerDev &Lp, const float *src, int t0, int nt, hipStream_t st) {
     if (nt <= 0) return;
-    const size_t need = (size_t)P.n_wg * nt * 64;
+    const size_t need = (size_t)P.n_wg * nt * kXfragLanes;
     hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, src, m->xfrag, P.nb, P.T,
                        Lp.K, P.nq, P.hp ? 1 : 0, P.n_wg, Lp.x_scale, m->oor_flag, t0, nt, sp ? *sp : SplitPlan{});
 }
@@ -1073,7 +1073,7 @@ int Pass::layer(int l) {
     int rc;
     if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
     if (fuse) {
-        const size_t need = (size_t)P.n_wg * T * 64;
+        const size_t need = (size_t)P.n_wg * T * kXfragLanes;
         if (need > m->xfrag_cap) {
             free_dev(m->xfrag); m->xfrag = nullptr; m->xfrag_cap = 0;
             HIP_TRY(hipMalloc((void **)&m->xfrag, need * sizeof(half8)));

@@ -32,6 +32,7 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
 }
 
+constexpr int kXfragLanes = 32;             // lanes of a packed layer-0 input block (k_pack_x): K + 1 <= 16 of the k-step's 32 slots
 constexpr int kHGroupStride = 272;          // bytes: 16 rows x 16 B + 16 B pad (bank spread)
 constexpr int kHKStride = 4 * kHGroupStride;  // one k-step (32 units) of the A image
 constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
@@ -63,7 +64,7 @@ constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
 template <int PF, int NQ, bool XIN, bool HP, int CELL = 0, int ABL = 0, bool DS = false>
 __global__ __launch_bounds__(512, 2) void k_rec_mfma(
     const float *__restrict__ gi,      // !XIN: gi_t (layout.hpp), folded bias, PRE-SCALED by S_d
-    const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][64 lanes]
+    const half8 *__restrict__ xfrag,   //  XIN: packed x A-fragments [work-group][t][kXfragLanes]
     const half8 *__restrict__ wxfrag,  //  XIN: W_ih (+bias row) B-fragments [D][8][3][2][64]
     const half8 *__restrict__ wfrag,   // W_hh B-fragments [D][8][4][3][2][64]
     const float *__restrict__ b_hn,    // [D][128]  (unscaled)
@@ -145,10 +146,12 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
         gp[q] = gi + gi_block(d, n_tiles, tile, T, t_first, NG) + gi_in_block(w8, lq, 0, llane, NG);
         op[q] = out + act_block(D, tile, T, t_first) + act_in_block(d, w8, lq, llane);
     }
-    const half8 *xp = xfrag + ((size_t)blockIdx.x * T + t_first) * 64 + lane;
+    // (only lane groups 0, 1 of the k-step carry data -- features, the bias row -- and W_ih's rows behind them are zero: the
+    // packed block is 32 lanes = 512 bytes, lanes 32..63 read a copy of lanes 0..31 that multiplies zeros)
+    const half8 *xp = xfrag + ((size_t)blockIdx.x * T + t_first) * kXfragLanes + (lane & (kXfragLanes - 1));
     const long gstride = tstep * gi_block_floats(NG);
     const long ostride = tstep * (long)(D * 1024);
-    const long xstride = tstep * 64;
+    const long xstride = tstep * kXfragLanes;
     float hprev[NQ];   // GRU: h_{t-1};  LSTM: the cell state c_{t-1}
 #pragma unroll
     for (int q = 0; q < NQ; ++q) hprev[q] = 0.f;
@@ -483,17 +486,17 @@ __global__ __launch_bounds__(512, 2) void k_rec_mfma(
 // exact fp32 projection kernel ON THE DEVICE (both paths are enqueued, the flag selects).
 static __global__ __launch_bounds__(256) void k_pack_x(
     const float *__restrict__ x,   // [B][T][I]
-    half8 *__restrict__ xfrag,     // [n_wg][T][64]
+    half8 *__restrict__ xfrag,     // [n_wg][T][kXfragLanes]
     int B, int T, int I, int nq, int hp, int n_wg, float sx, int *__restrict__ oor,
     int t_lo, int nt,              // columns [t_lo, t_lo + nt) of every window (the host path streams x in time slabs)
     SplitPlan sp)                  // sp.S > 1: B x T is the VIRTUAL batch of a split scan and x the real (sp.B, sp.T, I) one --
                                    // virtual window v = k * sp.B + w is columns [sp.start[k], +T) of window w (scan_split.hpp)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)n_wg * nt * 64;
+    const size_t total = (size_t)n_wg * nt * kXfragLanes;
     if (idx >= total) return;
-    const int lane = (int)(idx & 63);
-    const size_t wt = idx >> 6;
+    const int lane = (int)(idx & (kXfragLanes - 1));
+    const size_t wt = idx / kXfragLanes;
     const int t = t_lo + (int)(wt % nt);
     const int wg = (int)(wt / nt);
     const int row = lane & 15, gq = lane >> 4;
@@ -523,7 +526,7 @@ static __global__ __launch_bounds__(256) void k_pack_x(
         split_f16(val, hi, lo);
         v[i] = split ? lo : hi;
     }
-    xfrag[((size_t)wg * T + t) * 64 + lane] = v;
+    xfrag[((size_t)wg * T + t) * kXfragLanes + lane] = v;
     if (bad) atomicOr(oor, 1);
 }
 
