@@ -498,7 +498,7 @@ def main_rl(args, emit=True):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback of the engine")
-    dev = torch.device("cuda", ranks.local_rank)
+    dev = torch.device("cuda", ranks.local_rank if ranks.local_rank < torch.cuda.device_count() else 0)
     torch.cuda.set_device(dev)
     wide = args.model == "rl384"
     B = args.batch if args.batch != 200 else 100            # reference CLI default batch for these models
@@ -733,7 +733,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback of the engine")
-    dev = torch.device("cuda", 0 if args.shared_gpu else ranks.local_rank)
+    # (ranks that a launcher isolated with HIP_VISIBLE_DEVICES see one device each, index 0)
+    dev = torch.device("cuda", 0 if (args.shared_gpu or ranks.local_rank >= torch.cuda.device_count()) else ranks.local_rank)
     torch.cuda.set_device(dev)
 
     B, T = args.batch, args.chunk_len

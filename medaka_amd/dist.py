@@ -25,6 +25,7 @@ class Ranks:
         self.backend = backend
         self.fallback_reason = None
         self._pg = False
+        self.device_index = self.local_rank          # which visible HIP device this rank computes on (see below)
         if self.world > 1:
             import datetime
             import torch
@@ -42,9 +43,11 @@ class Ranks:
             if backend == "nccl":
                 err = None
                 try:
-                    if not torch.cuda.is_available() or torch.cuda.device_count() <= self.local_rank:
+                    if not torch.cuda.is_available() or torch.cuda.device_count() == 0:
                         raise RuntimeError(f"rank {self.rank}: no HIP device {self.local_rank} (device_count = {torch.cuda.device_count()})")
-                    torch.cuda.set_device(self.local_rank)
+                    # a launcher that isolates the ranks (HIP_VISIBLE_DEVICES per rank) shows each of them ONE device, index 0
+                    self.device_index = self.local_rank if self.local_rank < torch.cuda.device_count() else 0
+                    torch.cuda.set_device(self.device_index)
                 except Exception as exc:               # noqa: BLE001 -- whatever it is, this rank cannot take part in RCCL
                     err = f"{type(exc).__name__}: {exc}"
                 # phase A: does every rank have its device?  (nobody enters a collective that another rank cannot join)
@@ -56,7 +59,7 @@ class Ranks:
                     try:
                         dist.init_process_group(backend="nccl", store=dist.PrefixStore("mdk/nccl", store), rank=self.rank,
                                                 world_size=self.world, timeout=datetime.timedelta(seconds=nccl_timeout_s))
-                        t = torch.zeros(1, device=torch.device("cuda", self.local_rank))
+                        t = torch.zeros(1, device=torch.device("cuda", self.device_index))
                         dist.all_reduce(t)                    # the communicator is only built here
                         torch.cuda.synchronize()
                     except Exception as exc:                  # noqa: BLE001
@@ -95,7 +98,7 @@ class Ranks:
 
     def _device(self):
         import torch
-        return torch.device("cuda", self.local_rank) if self.backend == "nccl" else torch.device("cpu")
+        return torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
 
     def barrier(self):
         if self.world > 1:

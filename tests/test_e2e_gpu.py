@@ -283,6 +283,28 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
           f"({ratio:.2f} x); host-to-host {r2['host_to_host']['value'] / 1e6:.1f} M against {r1['host_to_host']['value'] / 1e6:.1f} M")
     assert 0.6 <= ratio <= 1.6, ratio
     assert r2["host_to_host"]["value"] > 0 and r2["roofline"]["kernels"]
+    assert r2["barrier_backend"] == "gloo" and r2["ranks_seen"] == 2
+
+
+def test_rccl_that_cannot_work_falls_back_on_hardware():
+    """`bench.py --gpus 2 --dry-ranks` with two ranks on the ONE visible GPU and NO `--shared-gpu`: `dist.Ranks` takes the RCCL
+    branch (what it does on the 8-GPU node), both ranks land on device 0, RCCL refuses -- or times out on -- duplicate
+    devices, and every rank must meet again on gloo: rc 0, `barrier_backend` gloo, a reason, both ranks seen.  The only way a
+    1-GPU box can execute the nccl branch of the N > 1 path at all."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29687", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(f"dry ranks on one GPU: {line}")
+    assert line["dry_ranks"] and line["ranks_seen"] == 2, line
+    # RCCL may also accept two ranks on one device on some stacks: then the line says nccl and has no reason
+    assert (line["barrier_backend"] == "gloo") == bool(line["fallback_reason"]), line
 
 
 def test_validate_tool_on_a_state_dict(gold, tmp_path):
