@@ -9,7 +9,7 @@
 //   * one 512-thread work-group (8 waves, two per SIMD) per (8-window tile, direction);
 //     wave w8 owns hidden units [16*w8, 16*w8+16) of all three gates = 3 MFMA column tiles;
 //   * W_hh lives in registers for the whole kernel as pre-packed fp16 hi/lo B-fragments
-//     (96 VGPRs per lane); h_t is staged in LDS as the fp16 hi/lo A-operand (4.25 KB, double
+//     (96 VGPRs per lane); h_t is staged in LDS as the fp16 hi/lo A-operand (4 KB, double
 //     buffered) -- zero global-memory round trips on the step-to-step dependency;
 //   * fp32 parity through an fp16x2 split: A rows = (window, hi|lo) -> 16 rows for 8 windows,
 //     B = W_hi then W_lo into fp32 accumulators, so  acc[row hi] + acc[row lo]
@@ -33,9 +33,15 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {
 }
 
 constexpr int kXfragLanes = 32;             // lanes of a packed layer-0 input block (k_pack_x): K + 1 <= 16 of the k-step's 32 slots
-constexpr int kHGroupStride = 272;          // bytes: 16 rows x 16 B + 16 B pad (bank spread)
+// One lane group of the A image: 16 rows x 16 B, NO pad.  ds_read_b128 is served in four groups of 16 lanes that mix
+// lanes of two lane groups ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS table): with rows 256 B apart those 16
+// lanes cover all 64 banks once; the 16-byte pad rounds 1-4 used (for the 2-byte publishes of the two half-groups of a
+// wave, which then share banks) made lanes 12 and 27 of every read meet on banks 48-51 -- and the reads move sixteen times
+// the bytes of the publishes.  Measured (profiles/r5_experiments/README.md): half precision 3.61 -> 3.50 ms per forward,
+// fp32 parity 6.34 -> 6.31; 288 is worse than 272.
+constexpr int kHGroupStride = 256;
 constexpr int kHKStride = 4 * kHGroupStride;  // one k-step (32 units) of the A image
-constexpr int kHBufBytes = 4 * kHKStride;     // 4352 B per buffer
+constexpr int kHBufBytes = 4 * kHKStride;     // 4096 B per buffer
 
 // Why 8 waves: measured on MI355X, a 4-wave version (one wave per SIMD, 6 tiles per wave) is
 // instruction-ISSUE bound (~250 instructions x ~4 cycles per step) -- removing all of its MFMAs
