@@ -235,6 +235,10 @@ typedef struct {
     int start[16], first[16], last[16];
 } mdk_split_shape;
 int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_split_shape *out);
+/* The margin learner (option "scan_split_adapt") on a model that certifies iff the margin is >= `need` (0: never): n_calls calls
+ * from margin `start`; margins[i] = the margin call i was answered at (0: sequentially), forwards[i] = the split forwards it cost.
+ * Device-free, for tests and for reasoning about what a model with a known forgetting length will pay. */
+int mdk_margin_sim(int start, int adapt, int need, int n_calls, int *margins, int *forwards);
 
 /* Device ordinal the model lives on (`TorchModel.device()`, models.py:291-296). */
 int mdk_gru_device(const mdk_gru *m);

@@ -36,6 +36,54 @@ using namespace mdk;
 extern "C" const char *mdk_last_error(void) { return g_mdk_err.c_str(); }
 extern "C" const char *mdk_version(void) { return "medaka_amd 0.1 (gfx950)"; }
 
+// ---- the margin of the split scan, learned per model (scan_split.hpp).  Pure state machine, no
+// device: also exported as mdk_margin_sim for the CPU property tests.
+// The margins a model can learn: a ladder instead of doublings (a set that needs 192 should not pay for 256: 19 % of all
+// columns against 25 %).  Margins outside the ladder (option "scan_split_margin") join it at the next rung.
+static const int kMarginLadder[] = {64, 96, 128, 192, 256, 384, 512};
+static int split_margin_up(int G) {
+    for (int r : kMarginLadder) if (r > G) return r;
+    return 2 * kSplitMarginMax;                      // above the ladder: the caller gives the model up
+}
+static int split_margin_down(int G, int floor_) {
+    int best = 0;
+    for (int r : kMarginLadder) if (r < G && r >= floor_) best = r;
+    return best;                                     // 0: nothing smaller is allowed
+}
+struct MarginLearner {
+    int cur = 0;          // margin in use (0: the option's starting margin)
+    int floor_ = 0;       // no shrink below this: one rung above the largest margin a certificate was ever rejected at
+    int quiet = 0;        // consecutive certified calls at the current margin whose differences sat at the noise floor
+    int trial_back = 0;   // != 0: the current margin is a shrink on trial; a rejection returns to this one
+    enum Next { RETRY = 0, GIVE_UP = 1 };
+    void reset(bool forget_rejections) { cur = quiet = trial_back = 0; if (forget_rejections) floor_ = 0; }
+    // a certified call at margin G; returns the margin a kept trial came from (0: none).  `adapt` = quiet calls before a smaller
+    // margin is tried (0: never), `noise_floor` = largest junction difference that still counts as quiet
+    int certified(int G, float worst, float noise_floor, int adapt) {
+        const int was = trial_back;
+        trial_back = 0;
+        quiet = worst <= noise_floor ? quiet + 1 : 0;
+        if (adapt > 0 && quiet >= adapt) {
+            const int down = split_margin_down(G, floor_);
+            quiet = 0;
+            if (down) { trial_back = G; cur = down; }
+        }
+        return was;
+    }
+    // a rejected certificate at margin G: RETRY = run the call again at `cur` (a failed trial goes back, anything else one rung
+    // up), GIVE_UP = nothing larger is left.  `*back` = 1 if this was a trial
+    Next rejected(int G, int *back) {
+        quiet = 0;
+        floor_ = std::max(floor_, split_margin_up(G));          // never shrink to a rejected margin again
+        *back = 0;
+        if (trial_back) { cur = trial_back; trial_back = 0; *back = 1; return RETRY; }
+        const int next = split_margin_up(G);
+        if (next > kSplitMarginMax) return GIVE_UP;
+        cur = next;
+        return RETRY;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // model object
 struct LayerDev {
@@ -103,12 +151,9 @@ struct mdk_gru {
     // split scan (scan_split.hpp)
     int opt_scan_split = 1;                  // 0 off, 1 auto, n >= 2: n chunks per window whenever the shape allows it
     int opt_split_margin = 128;              // G: columns of warm-up on either side of a chunk (where the model starts)
-    int split_margin_cur = 0;                // margin in use (0: opt_split_margin): LEARNED per model -- one rung up the ladder 64 .. 512 on a
-                                             // rejected certificate, one rung down after `opt_split_adapt` certified calls at the noise floor
+    MarginLearner margin;                    // the margin in use, LEARNED per model: one rung up the ladder 64 .. 512 on a rejected
+                                             // certificate, one rung down after `opt_split_adapt` certified calls at the noise floor
     int opt_split_adapt = 8;                 // certified calls at the noise floor before a smaller margin is tried (0: never shrink)
-    int split_margin_floor = 0;              // no shrink below this: one rung above the largest margin a certificate was ever rejected at
-    int split_quiet = 0;                     // consecutive certified calls at the current margin with differences <= a quarter of the threshold
-    int split_trial_back = 0;                // != 0: the current margin is a shrink on trial; a rejection returns to this one
     bool split_disabled = false;             // a certificate failed at the largest margin (or an audit failed): sequential scans (auto mode)
     long split_retry_in = 0;                 // ... for this many calls; then one more try at the largest margin (0: for good -- failed audits)
     long split_backoff = 0;                  // the last back-off (doubles per rejection at the largest margin: 64 .. 4096 calls)
@@ -430,7 +475,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->opt_scan_split = value;
         m->split_disabled = false;           // setting the option re-arms a model that fell back
         m->split_retry_in = m->split_backoff = 0;
-        m->split_margin_floor = m->split_quiet = m->split_trial_back = 0;
+        m->margin.reset(true);
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
@@ -440,12 +485,11 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     } else if (!strcmp(key, "scan_split_adapt")) {
         if (value < 0) return fail(MDK_ERR_ARG, "scan_split_adapt must be >= 0 (certified calls at the noise floor before a smaller margin is tried; 0 = never)");
         m->opt_split_adapt = value;
-        m->split_quiet = 0;
+        m->margin.quiet = 0;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
-        m->split_margin_cur = 0;
-        m->split_quiet = m->split_trial_back = 0;      // (what the certificates rejected so far stays learned: "scan_split" re-arms)
+        m->margin.reset(false);      // (what the certificates rejected so far stays learned: "scan_split" re-arms)
         m->split_disabled = false;
         m->split_retry_in = m->split_backoff = 0;
     } else {
@@ -1293,6 +1337,28 @@ static bool plan_split_shape(int B, int T, int share, int mode, int G, size_t bu
     return true;
 }
 
+// The margin learner on a model that certifies iff the margin is >= `need` (0: never), with differences at the noise floor:
+// n_calls calls from `start`; margins[i] = the margin call i was ANSWERED at (0: sequentially), forwards[i] = split forwards
+// it cost (rejected ones included).  Device-free: the CPU tests drive the state machine through this.
+extern "C" int mdk_margin_sim(int start, int adapt, int need, int n_calls, int *margins, int *forwards) {
+    if (start < 16 || start > 4096 || adapt < 0 || need < 0 || n_calls < 0 || !margins || !forwards)
+        return fail(MDK_ERR_ARG, "bad argument");
+    MarginLearner L;
+    bool disabled = false;
+    for (int i = 0; i < n_calls; ++i) {
+        margins[i] = 0; forwards[i] = 0;
+        if (disabled) continue;
+        for (;;) {
+            const int G = L.cur ? L.cur : start;
+            forwards[i]++;
+            if (need > 0 && G >= need) { L.certified(G, 0.f, 1.f, adapt); margins[i] = G; break; }
+            int back = 0;
+            if (L.rejected(G, &back) == MarginLearner::GIVE_UP) { disabled = true; break; }
+        }
+    }
+    return MDK_OK;
+}
+
 extern "C" int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_split_shape *out) {
     if (!out) return fail(MDK_ERR_ARG, "null argument");
     if (B < 0 || T < 0 || gpu_share < 1 || gpu_share > 8 || scan_split < 0 || scan_split > kMaxSplit || margin < 16 || margin > 4096 || margin % 8)
@@ -1306,26 +1372,13 @@ extern "C" int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int m
     return MDK_OK;
 }
 
-// The margins a model can learn: a ladder instead of doublings (a set that needs 192 should not pay for 256: 19 % of all
-// columns against 25 %).  Margins outside the ladder (option "scan_split_margin") join it at the next rung.
-static const int kMarginLadder[] = {64, 96, 128, 192, 256, 384, 512};
-static int split_margin_up(int G) {
-    for (int r : kMarginLadder) if (r > G) return r;
-    return 2 * kSplitMarginMax;                      // above the ladder: the caller gives the model up
-}
-static int split_margin_down(int G, int floor_) {
-    int best = 0;
-    for (int r : kMarginLadder) if (r < G && r >= floor_) best = r;
-    return best;                                     // 0: nothing smaller is allowed
-}
-
 static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
     static const int env_abl = getenv("MDK_ABLATE") ? atoi(getenv("MDK_ABLATE")) : 0;
     p.S = 1;
     if (m->opt_scan_split == 0 || (m->split_disabled && m->opt_scan_split == 1)) return false;
     if (m->variant != MDK_VARIANT_MFMA || m->D != 2 || m->desc.num_layers != 2 || m->opt_ablate || env_abl) return false;
     if (m->layers[0].K > 16) return false;
-    return plan_split_shape(B, T, m->opt_gpu_share, m->opt_scan_split, m->split_margin_cur ? m->split_margin_cur : m->opt_split_margin,
+    return plan_split_shape(B, T, m->opt_gpu_share, m->opt_scan_split, m->margin.cur ? m->margin.cur : m->opt_split_margin,
                             m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass, p);
 }
 
@@ -1442,17 +1495,9 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
             // forgetting length: after `scan_split_adapt` certified calls in a row whose largest junction difference sat at the
             // rounding-noise floor (a quarter of the threshold), the next call tries one rung less.  A trial that is rejected
             // costs that one forward: the call is repeated at the margin that worked, and no shrink goes below it again.
-            if (m->split_trial_back) {
-                fprintf(stderr, "[medaka_amd] split scan: certified at a margin of %d columns (was %d): kept\n", sp.G, m->split_trial_back);
-                m->split_trial_back = 0;
-            }
             const float quiet_thr = 0.25f * (m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps);
-            m->split_quiet = m->last_split.max_delta <= quiet_thr ? m->split_quiet + 1 : 0;
-            if (m->opt_scan_split == 1 && m->opt_split_adapt > 0 && m->split_quiet >= m->opt_split_adapt) {
-                const int down = split_margin_down(sp.G, m->split_margin_floor);
-                m->split_quiet = 0;
-                if (down) { m->split_trial_back = sp.G; m->split_margin_cur = down; }
-            }
+            const int was = m->margin.certified(sp.G, m->last_split.max_delta, quiet_thr, m->opt_scan_split == 1 ? m->opt_split_adapt : 0);
+            if (was) fprintf(stderr, "[medaka_amd] split scan: certified at a margin of %d columns (was %d): kept\n", sp.G, was);
             // Audit.  The certificate argues from the states at the junctions; the audit looks at what is delivered: the call is
             // ALSO run as the sequential scan on the device and the two (B, T, C) results are compared in full.  Audited are the
             // first certified call of a model (and the first at every margin / precision it moves to) and, as a STANDING check on
@@ -1515,19 +1560,18 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         // a rejection AT kSplitMarginMax: a very long or chaotic memory.  A forced chunk count is not second-guessed: the
         // call is answered sequentially.
         m->last_split.fallbacks++;
-        m->split_quiet = 0;
+        m->margin.quiet = 0;
         if (m->opt_scan_split != 1) break;
-        m->split_margin_floor = std::max(m->split_margin_floor, split_margin_up(sp.G));     // never shrink to a rejected margin again
-        if (m->split_trial_back) {
+        int was_trial = 0;
+        const MarginLearner::Next nx = m->margin.rejected(sp.G, &was_trial);
+        if (was_trial) {
             // a shrink on trial did not certify: back to the margin that did (this call is repeated there)
             fprintf(stderr, "[medaka_amd] split scan: a margin of %d columns does not certify (junction states differ by %.3g): back to %d\n",
-                    sp.G, m->last_split.max_delta, m->split_trial_back);
-            m->split_margin_cur = m->split_trial_back;
-            m->split_trial_back = 0;
+                    sp.G, m->last_split.max_delta, m->margin.cur);
             continue;
         }
-        const int next = split_margin_up(sp.G);
-        if (next > kSplitMarginMax) {
+        const int next = m->margin.cur;
+        if (nx == MarginLearner::GIVE_UP) {
             m->split_disabled = true;
             m->split_backoff = m->split_backoff ? std::min<long>(2 * m->split_backoff, 4096) : 64;
             m->split_retry_in = m->split_backoff;
@@ -1537,7 +1581,6 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
                         m->last_split.max_delta, sp.G, m->split_backoff);
             break;
         }
-        m->split_margin_cur = next;
         fprintf(stderr, "[medaka_amd] split scan: junction states differed by %.3g at a margin of %d columns: margin %d from now on\n",
                 m->last_split.max_delta, sp.G, next);
     }

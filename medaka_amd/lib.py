@@ -71,6 +71,7 @@ ABI = {
     "mdk_gru_stage_input": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mdk_gru_forward_staged": (_i, [_vp, ctypes.c_ulonglong, _i, _i, _vp]),
     "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
+    "mdk_margin_sim": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),
     "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),

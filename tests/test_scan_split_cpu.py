@@ -115,3 +115,49 @@ def test_premise_on_the_reference_arithmetic(gold):
             assert d <= bound, (name, scale, d)
         else:
             assert d > 1e-2, (name, scale, d)
+
+
+# ---- the margin learner (api.hip MarginLearner, exported device-free as mdk_margin_sim) -----------------------------------
+LADDER = (64, 96, 128, 192, 256, 384, 512)
+
+
+def _sim(start, adapt, need, n):
+    import ctypes
+    from medaka_amd import lib
+    m, f = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    lib.check(lib.load().mdk_margin_sim(start, adapt, need, n, m, f), "mdk_margin_sim")
+    return list(m), list(f)
+
+
+@pytest.mark.parametrize("need", LADDER)
+def test_margin_learner_settles_at_what_the_model_needs(need):
+    """A model that certifies iff the margin is >= `need`: from the default 128 the learner ends at exactly `need`, climbs one
+    rung per rejection (never a doubling), shrinks one rung per `adapt` quiet calls, pays at most one wasted forward per
+    rejected trial -- one, ever -- and every call is answered at a margin that certifies."""
+    margins, forwards = _sim(128, 8, need, 200)
+    assert all(g >= need and g in LADDER for g in margins), margins[:40]
+    assert margins[-1] == need
+    if need > 128:          # climbs during the FIRST call: one forward per rung
+        rungs = [r for r in LADDER if 128 <= r <= need]
+        assert forwards[0] == len(rungs) and margins[0] == need and set(forwards[1:]) == {1}
+    else:                   # shrinks: need's rung reached after (rungs down) x 8 quiet calls, then ONE rejected trial below it (if there is a rung below)
+        down = [r for r in LADDER if need <= r <= 128][::-1]
+        assert margins[:8] == [128] * 8
+        settle = 8 * (len(down) - 1)
+        assert margins[settle] == need
+        wasted = sum(f - 1 for f in forwards)
+        assert wasted == (1 if need > 64 else 0), (wasted, forwards[:60])
+        assert sorted(margins, reverse=True) == margins           # never back up
+    # the steady state is one forward per call
+    assert forwards[-50:] == [1] * 50
+
+
+def test_margin_learner_never_retries_a_rejected_margin_and_gives_up_beyond_the_ladder():
+    margins, forwards = _sim(128, 3, 96, 100)            # 64 is tried once (after 3 quiet calls at 96), rejected, never again
+    assert margins[-1] == 96 and sum(f - 1 for f in forwards) == 1
+    margins, forwards = _sim(128, 8, 0, 10)              # never certifies: 128, 192, 256, 384, 512 in the first call, then sequential
+    assert forwards[0] == 5 and margins == [0] * 10 and forwards[1:] == [0] * 9
+    margins, forwards = _sim(32, 8, 192, 5)              # a starting margin below the ladder joins it at the next rung
+    assert margins[0] == 192 and forwards[0] == 5        # 32, 64, 96, 128 rejected, 192 certified
+    margins, forwards = _sim(128, 0, 64, 50)             # adapt = 0: margins only grow
+    assert set(margins) == {128} and set(forwards) == {1}
