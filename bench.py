@@ -863,11 +863,13 @@ def main():
                [("page-locked (engine collate)", x_cpu.pin_memory()), ("pageable (reference collate)", x_cpu)]
     if args.stream_host is not None:
         eng.set_option("stream_host", args.stream_host)
-    # The box's power management is part of this number.  Straight after a stretch of device-resident work the 2-D DMA
-    # copies that carry finished columns home run at a third of their rate for the next ~15 calls (150-200 ms; measured:
-    # profiles/r4_experiments/README.md "host-to-host after a compute burst"), then settle -- a prediction run is in the settled
-    # state from its first second on.  So: the first calls are recorded as they come (`first_calls_ms`), untimed calls follow
-    # until `settle_s` seconds of host-path traffic have passed (at least 8 calls), and the median is taken over the timed calls after those.
+    # The first calls are recorded as they come (`first_calls_ms`), untimed calls follow until `settle_s` seconds of host-path
+    # traffic have passed (at least 8 calls), and the median is taken over the timed calls after those.  Why: device memory
+    # handed back to the driver (hipFree) is wiped by the kernel on the DMA engines, in the background, at ~25 GB/s -- and while
+    # that runs every strided copy of the host path takes 130 us longer (10.9 instead of 8.0 ms per call).  Until round 5 every
+    # audit of the split scan freed 12 GB of gi workspace, so the ~40 calls behind each were slow ("the box's DMA needs 0.3 s to
+    # wake up", profiles/r4_experiments/README.md); the audit allocates nothing now (profiles/r5_experiments/README.md section 9)
+    # and the first calls are at the settled rate unless something else in the process has just freed device memory.
     h2h_all, first_calls = {}, {}
     settle_s, settle = 0.6, 0
     for vname, xv in variants:
@@ -935,8 +937,9 @@ def main():
                     "time (so nothing of it is on the device beforehand), median over the timed batches, max over ranks; a split "
                     "call copies x in once, in front of the forward, and sends the probabilities home in column chunks (2-D DMA copies) "
                     "under the second half of the last layer's scan, which writes them itself (rec_fused.hpp HEAD = 2); "
-                    "`first_calls_ms`: the calls straight after the device-resident section, while the box's DMA is still in the "
-                    "slow state a compute burst leaves it in (profiles/r4_experiments/README.md); the fed loop below hands every "
+                    "`first_calls_ms`: the calls straight after the device-resident section as they came (through round 4: 11 ms each "
+                    "-- the driver was wiping the 12 GB an audit had just freed, on the DMA engines; the audit frees nothing now: "
+                    "profiles/r5_experiments/README.md section 9); the fed loop below hands every "
                     "NEW batch to the device from the Batcher thread, so there the input does not wait for PCIe",
             "one_copy_each_way_ms_per_batch": 1e3 * statistics.median(plain),
         },
@@ -1041,11 +1044,11 @@ def main():
         cnt = np.minimum(np.rint(x_host * 60.0), 65535).astype(np.uint16)
         dep = np.full(x_host.shape[:2], 60, dtype=np.uint32)
         diet = []
-        for _ in range(4):
+        for _ in range(8):       # (the first calls allocate the aux buffers and the page-locked results)
             t0 = time.perf_counter()
-            model.predict_on_counts(cnt, dep, decoded=True)
+            out_holder["diet"] = model.predict_on_counts(cnt, dep, decoded=True)
             diet.append(time.perf_counter() - t0)
-        result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[1:])
+        result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[3:])
     if ranks.world == 1 and not args.shared_gpu and not args.half and args.extra_half:
         # the precision `medaka inference` selects on a GPU by default, on the same line (reference prediction.py:164-168)
         try:

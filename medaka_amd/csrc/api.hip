@@ -644,7 +644,8 @@ struct PassPlan {
     bool need_gi = true;
 };
 
-static int plan_pass(const mdk_gru *m, int nb, int T, const HostIO *io, const SplitPlan *sp, PassPlan &P, bool host_checks_range = false) {
+static int plan_pass(const mdk_gru *m, int nb, int T, const HostIO *io, const SplitPlan *sp, PassPlan &P, bool host_checks_range = false,
+                     bool lean = false) {
     P = PassPlan{};
     P.nb = nb; P.T = T; P.D = m->D; P.L = m->desc.num_layers;
     P.exact = (m->variant == MDK_VARIANT_EXACT);
@@ -676,6 +677,9 @@ static int plan_pass(const mdk_gru *m, int nb, int T, const HostIO *io, const Sp
     // half precision: 8-window work-groups while they fit the chip, so that layers >= 1 can run fused (rec_fused.hpp carries
     // 8 windows; 16-window groups fill only half the CUs at 1000 chunk-windows)
     if (P.hp && nq == 4 && m->opt_fuse_proj && L >= 2 && ((n_win + 7) / 8) * D * m->opt_gpu_share <= 256) nq = 2;
+    // `lean` (the audit's sequential scan): whatever the batch, the regime that needs no gi in HBM -- 8-window work-groups with
+    // the projection inside the recurrence -- so that an audit allocates nothing (and, above all, FREES nothing: see run_forward)
+    if (lean && nq < 2 && m->opt_fuse_proj && L >= 2) nq = 2;
     if (m->opt_tile_windows == 4) nq = 1;
     if (m->opt_tile_windows == 8) nq = 2;
     if (m->opt_tile_windows == 16 && P.hp) nq = 4;
@@ -700,7 +704,7 @@ static int plan_pass(const mdk_gru *m, int nb, int T, const HostIO *io, const Sp
     // (rec_fused.hpp; bit-identical to the GEMM + recurrence pair).  fp32-parity or half mode, 8-window work-groups, T a
     // multiple of the strip.  "fuse_proj" = 2 prefers it to the side-stream GEMM as well.
     P.fuse_proj = L >= 2 && nq == 2 && !P.ablated && T % kFusedSteps == 0 &&
-                  (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && P.n_wg * D * m->opt_gpu_share > kOvMaxWgs));   // auto: the recurrence fills the chip
+                  (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && (lean || P.n_wg * D * m->opt_gpu_share > kOvMaxWgs)));   // auto: the recurrence fills the chip
     P.overlap = overlap_ok && !P.fuse_proj;
     // ... and with it the classifier's Linear (rec_fused.hpp HEAD): the last layer leaves partial logits, k_head_combine
     // finishes them (fp16x2-split MFMA instead of fp32 FMAs: ~1e-7 relative on the logits, not bit for bit)
@@ -1278,9 +1282,10 @@ static int finish_timing(mdk_gru *m, EvTimer &tm, hipStream_t s) {
     return MDK_OK;
 }
 
-// all passes of one call; x_host / probs_host (may be null) select the streamed host path per pass
+// all passes of one call; x_host / probs_host (may be null) select the streamed host path per pass.  `lean`: plan for the
+// regime without gi (plan_pass); the CALLER looks at the range flag afterwards (range_flag_raised) and repeats without it
 static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
-                      const float *x_host, float *probs_host) {
+                      const float *x_host, float *probs_host, bool lean = false) {
     memset(&m->last, 0, sizeof(m->last));
     m->last.n_layers = m->desc.num_layers;
     // windows per pass, bounded so that the workspace stays within a fixed column budget
@@ -1292,8 +1297,15 @@ static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs
     size_t per_pass = ((size_t)B + n_pass - 1) / n_pass;
     if (n_pass > 1 && fit >= kTileWin)             // full recurrence tiles in all but the last pass
         per_pass = std::min(fit - fit % kTileWin, (per_pass + kTileWin - 1) / kTileWin * kTileWin);
-    int rc = ensure_workspace(m, ((per_pass + kTileWin - 1) / kTileWin * kTileWin) * (size_t)T, true);
-    if (rc) return rc;
+    int rc;
+    if (n_pass > 1) lean = false;                  // (the range flag is per pass: only a single pass can leave it to the caller)
+    bool need_gi = !lean;
+    if (lean) {
+        PassPlan P;
+        if ((rc = plan_pass(m, (int)std::min(per_pass, (size_t)B), T, nullptr, nullptr, P, true, true))) return rc;
+        need_gi = P.need_gi;
+    }
+    if ((rc = ensure_workspace(m, ((per_pass + kTileWin - 1) / kTileWin * kTileWin) * (size_t)T, need_gi))) return rc;
     EvTimer tm{m, s};
     const size_t F = m->desc.num_features, C = m->desc.num_classes;
     for (size_t b0 = 0; b0 < (size_t)B; b0 += per_pass) {
@@ -1303,7 +1315,7 @@ static int run_passes(mdk_gru *m, const float *x_dev, int B, int T, float *probs
         if (probs_host) io.p_host = probs_host + b0 * T * C;
         const HostIO *iop = (x_host || probs_host) ? &io : nullptr;
         PassPlan P;                                  // (the range flag is per pass: the fallback stays on the device here)
-        if ((rc = plan_pass(m, nb, T, iop, nullptr, P))) return rc;
+        if ((rc = plan_pass(m, nb, T, iop, nullptr, P, lean, lean))) return rc;
         if ((rc = forward_pass(m, P, x_dev + b0 * T * F, probs_dev + b0 * T * C, s, tm, iop))) return rc;
     }
     return finish_timing(m, tm, s);
@@ -1517,17 +1529,25 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
                 m->audit_cap = n;
             }
             const mdk_gru_split certified = m->last_split;
-            const bool gi_before = m->gi_rows != 0, gi2_before = m->gi2_rows != 0;
-            rc = run_passes(m, x_dev, B, T, m->audit, s, nullptr, nullptr);      // (x_dev holds x also on the host path)
+            // (x_dev holds x also on the host path.)  The audit's scan is planned `lean`: it needs no gi -- 6 GB per buffer at
+            // 200 x 10 000, which an audit used to allocate and give back: memory handed back to the driver is wiped by the
+            // kernel ON THE DMA ENGINES, in the background, and while that ran (0.45 s for the two buffers) every strided copy of
+            // the host path took 130 us longer -- the "slow DMA state" of the first 40 calls after every audit, found in round 5
+            // (profiles/r5_experiments/README.md section 9).
+            rc = run_passes(m, x_dev, B, T, m->audit, s, nullptr, nullptr, /*lean=*/true);
             if (rc) return rc;
+            if (!m->oor_seen) {             // (possibly) no gi, no device-side fallback: was x inside fp16 range?  (if not: once more, with it)
+                bool raised = false;
+                if ((rc = range_flag_raised(m, s, &raised))) return rc;
+                if (raised && (rc = run_passes(m, x_dev, B, T, m->audit, s, nullptr, nullptr))) return rc;
+            }
             HIP_TRY(hipMemsetAsync(m->split_flag, 0, sizeof(unsigned), s));
             hipLaunchKernelGGL(k_split_audit, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, s,
                                (const float *)probs_dev, (const float *)m->audit, n, m->split_flag);
             HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            // (the sequential scan projects through HBM: its gi buffers go back if this audit was all they were for)
-            if (!gi_before) { free_dev(m->gi); m->gi = nullptr; m->gi_rows = 0; }
-            if (!gi2_before) { free_dev(m->gi2); m->gi2 = nullptr; m->gi2_rows = 0; }
+            // (a shape whose sequential scan cannot run fused -- T not a multiple of the strip -- did allocate gi: it STAYS, the
+            // next audit of the shape needs it again and a hipFree of that size is 0.5 s of slow strided DMA, see above)
             float dp;
             memcpy(&dp, &m->split_host[0], sizeof(float));
             m->audits_done++;

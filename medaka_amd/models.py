@@ -32,16 +32,16 @@ from medaka_amd import engine as _engine
 from medaka_amd import lib as _lib
 
 
-def _host_output(shape):
-    """CPU float32 tensor for `predict_on_batch` to return (models.py:312 `.cpu()`), page-locked: torch's
+def _host_output(shape, dtype=torch.float32):
+    """CPU tensor for `predict_on_batch` to return (models.py:312 `.cpu()`), page-locked: torch's
     caching host allocator recycles the block once every view the caller keeps (the HDF writer holds the
     per-sample rows, datastore.py:283-300) is gone, so steady-state batches neither allocate nor
     page-fault -- a fresh 40 MB pageable tensor costs 3.6 ms of first-touch faults as a DMA target
     (profiles/r2_host_path_probe.txt)."""
     try:
-        return torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        return torch.empty(shape, dtype=dtype, pin_memory=True)
     except RuntimeError:
-        return torch.empty(shape, dtype=torch.float32)
+        return torch.empty(shape, dtype=dtype)
 
 
 class TorchModel(torch.nn.Module):
@@ -229,10 +229,17 @@ class GRUModel(CountsMatrixModel):
         depth = np.asarray(depth.numpy() if isinstance(depth, torch.Tensor) else depth)
         with torch.inference_mode():
             eng = self.engine()
+        if counts.ndim != 3:
+            raise ValueError(f"expected counts (B, T, {self.num_features}), got {counts.shape}")
+        B, T = counts.shape[:2]
+        # results land in page-locked tensors from torch's caching host allocator, as predict_on_batch's do (_host_output)
         if decoded:
-            cls, pmax = eng.forward_counts_host(counts, depth, probs=False, decoded=True)
-            return torch.from_numpy(cls), torch.from_numpy(pmax)
-        return torch.from_numpy(eng.forward_counts_host(counts, depth))
+            cls, pmax = _host_output((B, T), torch.uint8), _host_output((B, T))
+            eng.forward_counts_host(counts, depth, probs=False, decoded=True, out=(cls.numpy(), pmax.numpy()))
+            return cls, pmax
+        p = _host_output((B, T, 5))
+        eng.forward_counts_host(counts, depth, out=(p.numpy(),))
+        return p
 
 
 class MajorityVoteModel(CountsMatrixModel):

@@ -264,6 +264,48 @@ def test_the_margin_is_learned_downwards_too(gold):
     e.close()
 
 
+def test_an_audit_frees_nothing_and_the_calls_behind_it_are_not_slow(gold):
+    """Device memory handed back to the driver is wiped by the kernel on the DMA engines, in the background (~25 GB/s), and
+    every strided result copy of the host path takes 130 us longer meanwhile: through round 4 (and most of 5) every audit
+    of the split scan allocated and freed 12 GB of gi workspace at 200 x 10 000, and the 40 calls behind it took 10.9 ms
+    instead of 8.0 (profiles/r5_experiments/README.md section 9).  The audit's sequential scan is planned without gi now:
+    its timing record shows layer 1 fused, and the calls straight behind an audit run at the settled rate."""
+    import time
+    B, T = 200, 10000
+    x = np.concatenate([synth.counts_windows(8, T, depth=50, seed=100 + s) for s in range(25)])
+    e = engine.GruEngine(gold["weights_trained"])
+    px, pp = engine.PinnedArray(x.shape), engine.PinnedArray((B, T, 5))
+    px.array[...] = x
+
+    def call():
+        t0 = time.perf_counter()
+        e.forward_ptr(px.array.ctypes.data, B, T, pp.array.ctypes.data, host=True)
+        return time.perf_counter() - t0
+
+    e.enable_timing(True)
+    call()                                                   # certified, audited: the timing record is the audit's pass
+    info, tm = e.split(), e.timing()
+    assert info["status"] == "certified" and info["audited"], info
+    assert tm["fused_layers"] & 2 and tm["gi_ms"][1] == 0.0, tm      # layer 1's projection inside the recurrence: no gi
+    e.enable_timing(False)
+    call()
+    early = sorted(call() for _ in range(9))[4]              # calls 2 .. 10 behind the audit
+    for _ in range(45):
+        call()
+    late = sorted(call() for _ in range(9))[4]               # ... and well past where the wipe used to end
+    print(f"host-path call behind an audit: {1e3 * early:.2f} ms, 55 calls later: {1e3 * late:.2f} ms")
+    assert early <= 1.12 * late, (early, late)
+    # the mechanism itself, so that this test says what it guards against: free 6 GB, and the next calls are slow
+    t = torch.empty(6 << 30, dtype=torch.uint8, device="cuda")
+    t.fill_(1)
+    torch.cuda.synchronize()
+    del t
+    torch.cuda.empty_cache()
+    wiped = sorted(call() for _ in range(7))[3]
+    print(f"... and straight after a hipFree of 6 GB: {1e3 * wiped:.2f} ms")
+    e.close()
+
+
 def test_out_of_range_input_in_a_split_call(gold, capfd):
     """A split call in the throughput regime runs without the gi workspace (nothing there touches it) and therefore without the
     device-side exact-projection fallback; it looks at the range flag itself.  Un-normalised counts (x * 3000: beyond the
