@@ -201,7 +201,10 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   also run as the sequential scan and the two
  *                                                   results are compared in full (1e-5; half precision 4e-4); a mismatch
  *                                                   delivers the sequential result and turns the split off.  One extra
- *                                                   forward per model.  2: every certified call (debug), 0: never
+ *                                                   forward per model (it allocates no workspace of its own and frees none:
+ *                                                   device memory handed back to the driver is wiped on the DMA engines, and
+ *                                                   the host path's result copies wait behind that).  2: every certified
+ *                                                   call (debug), 0: never
  *   "scan_split_audit_every" = 256 | n >= 0         standing audit: with "scan_split_audit" = 1, every n-th certified call after
  *                                                   the first is audited the same way (0: only the first of every margin);
  *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
