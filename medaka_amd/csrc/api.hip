@@ -1821,22 +1821,33 @@ extern "C" int mdk_majority_forward_dev(const float *x_dev, long n_cols, float *
     return MDK_OK;
 }
 
+// (the host entry's device buffers are kept per device, grow-only: a hipMalloc / hipFree pair per call costs milliseconds, and
+// freed device memory is wiped by the driver on the DMA engines -- behind which any engine's strided result copies wait)
+namespace {
+struct MajorityBuffers { std::mutex mu; float *x = nullptr, *p = nullptr; size_t cols = 0; };
+MajorityBuffers g_majority[16];
+}
+
 extern "C" int mdk_majority_forward(const float *x_host, long n_cols, float *probs_host, int device) {
     if (n_cols < 0) return fail(MDK_ERR_ARG, "negative n_cols");
     if (n_cols == 0) return MDK_OK;
     if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
+    if (device < 0 || device >= 16) return fail(MDK_ERR_ARG, "device %d out of range", device);
     HIP_TRY(hipSetDevice(device));
-    float *xd = nullptr, *pd = nullptr;
-    HIP_TRY(hipMalloc((void **)&xd, (size_t)n_cols * 10 * sizeof(float)));
-    hipError_t e = hipMalloc((void **)&pd, (size_t)n_cols * 5 * sizeof(float));
-    if (e != hipSuccess) { (void)hipFree(xd); return fail(MDK_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e)); }
-    int rc = MDK_OK;
-    if (hipMemcpy(xd, x_host, (size_t)n_cols * 10 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(MDK_ERR_DEVICE, "H2D copy failed");
-    if (!rc) rc = mdk_majority_forward_dev(xd, n_cols, pd, device, nullptr);
-    if (!rc && hipMemcpy(probs_host, pd, (size_t)n_cols * 5 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    MajorityBuffers &b = g_majority[device];
+    std::lock_guard<std::mutex> lock(b.mu);
+    if ((size_t)n_cols > b.cols) {
+        free_dev(b.x); free_dev(b.p); b.x = b.p = nullptr; b.cols = 0;
+        HIP_TRY(hipMalloc((void **)&b.x, (size_t)n_cols * 10 * sizeof(float)));
+        hipError_t e = hipMalloc((void **)&b.p, (size_t)n_cols * 5 * sizeof(float));
+        if (e != hipSuccess) { free_dev(b.x); b.x = nullptr; return fail(MDK_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+        b.cols = (size_t)n_cols;
+    }
+    if (hipMemcpy(b.x, x_host, (size_t)n_cols * 10 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MDK_ERR_DEVICE, "H2D copy failed");
+    int rc = mdk_majority_forward_dev(b.x, n_cols, b.p, device, nullptr);
+    if (!rc && hipMemcpy(probs_host, b.p, (size_t)n_cols * 5 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(MDK_ERR_DEVICE, "D2H copy failed");
-    (void)hipFree(xd); (void)hipFree(pd);
     return rc;
 }
 
