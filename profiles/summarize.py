@@ -10,7 +10,9 @@ def main():
         "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), "
         "max(grid_x), max(grid_y), max(workgroup_x), max(lds_size), max(vgpr_count), "
         "max(accum_vgpr_count), max(sgpr_count), max(scratch_size) "
-        "from kernels group by name order by 6 desc").fetchall()
+        # (one row per kernel AND grid: the split scan's audit runs the same kernels once on the un-split batch -- 25 instead of
+        # 125 work-groups per direction, five times the columns each -- and must not be averaged into the timed launches)
+        "from kernels group by name, grid_x, grid_y order by 6 desc").fetchall()
     tot = sum(r[5] for r in rows) or 1
     lines = ["kernel,calls,avg_us,min_us,max_us,total_ms,percent,grid_x,grid_y,wg_x,lds_bytes,vgpr,agpr,sgpr,scratch"]
     for r in rows:
