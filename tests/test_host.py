@@ -68,6 +68,31 @@ def test_engine_rejects_bad_weights():
         engine.GruEngine(missing)
 
 
+def test_counts_entry_checks_its_arguments_before_any_device_call():
+    """`forward_counts_host`: dtype, range, shape and the caller's result buffers are checked on the host --
+    nothing below reaches the library (the handle is a dummy)."""
+    import types
+    from medaka_amd import engine
+    eng = types.SimpleNamespace(num_features=10, num_classes=5, _h=None)
+    call = engine.GruEngine.forward_counts_host
+    counts, depth = np.ones((2, 7, 10), np.uint16), np.ones((2, 7), np.uint32)
+    with pytest.raises(ValueError, match="must be integers"):
+        call(eng, counts.astype(np.float32), depth)
+    with pytest.raises(ValueError, match="65535"):
+        call(eng, counts.astype(np.int64) * 70000, depth)
+    with pytest.raises(ValueError, match="expected counts"):
+        call(eng, counts[:, :, :9], depth)
+    with pytest.raises(ValueError, match="expected counts"):
+        call(eng, counts, depth[:, :6])
+    with pytest.raises(ValueError, match="nothing requested"):
+        call(eng, counts, depth, probs=False, decoded=False)
+    good = (np.empty((2, 7), np.uint8), np.empty((2, 7), np.float32))
+    for bad in ((good[0],), (good[1], good[0]), (good[0], np.empty((2, 7), np.float64)), (good[0][:, ::2], good[1]),
+                (np.empty((2, 7, 5), np.float32),) + good):
+        with pytest.raises(ValueError, match="out must be"):
+            call(eng, counts, depth, probs=False, decoded=True, out=bad)
+
+
 def test_grumodel_mirrors_reference_interface():
     m = models.GRUModel(num_features=10, num_classes=5, gru_size=128)
     # state_dict keys are the stock nn.GRU / nn.Linear names (SURVEY 3.2)
