@@ -243,6 +243,23 @@ int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_
  * Device-free, for tests and for reasoning about what a model with a known forgetting length will pay. */
 int mdk_margin_sim(int start, int adapt, int need, int n_calls, int *margins, int *forwards);
 
+/* How a pass of `windows` windows of T columns would be launched (device-free: the decisions of api.hip's plan_pass, for tests,
+ * for `python -m medaka_amd.validate --plan-only` and for sizing): work-group granularity, what is fused, what streams, and
+ * whether the pass needs the gi workspace (3 KB per column and direction; the throughput regime and an audit's scan do not).
+ *   precision   MDK_PREC_*;  gpu_share  processes sharing the GPU;  host_io  bit 0: x comes from host memory, bit 1: the
+ *   probabilities go to host memory;  split_chunks  > 1: the pass is the virtual batch of a split call;
+ *   mode  bit 0: the caller looks at the fp16-range flag itself (split calls, host entries), bit 1: `lean` (an audit's scan),
+ *         bit 2: the model has met out-of-range input before */
+typedef struct mdk_pass_shape {
+    int windows_per_group;   /* 4, 8 or 16 */
+    int work_groups;         /* per direction */
+    int fuse_layer0, fuse_projection, fuse_head, final_head;
+    int overlap_gemm, stream_in, stream_out;
+    int needs_gi;
+} mdk_pass_shape;
+int mdk_pass_plan(const mdk_gru_desc *desc, int precision, int gpu_share, int windows, int T, int host_io, int split_chunks,
+                  int mode, mdk_pass_shape *out);
+
 /* Device ordinal the model lives on (`TorchModel.device()`, models.py:291-296). */
 int mdk_gru_device(const mdk_gru *m);
 void mdk_gru_destroy(mdk_gru *m);

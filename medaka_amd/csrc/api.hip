@@ -1371,6 +1371,40 @@ extern "C" int mdk_margin_sim(int start, int adapt, int need, int n_calls, int *
     return MDK_OK;
 }
 
+// plan_pass on a model that exists on paper only (default options): nothing here touches a device
+extern "C" int mdk_pass_plan(const mdk_gru_desc *desc, int precision, int gpu_share, int windows, int T, int host_io, int split_chunks,
+                             int mode, mdk_pass_shape *out) {
+    if (!desc || !out) return fail(MDK_ERR_ARG, "null argument");
+    if (windows < 1 || T < 1 || gpu_share < 1 || gpu_share > 8 || split_chunks < 0 || split_chunks > kMaxSplit ||
+        (precision != MDK_PREC_FP32 && precision != MDK_PREC_FP16) || desc->num_layers < 1 || desc->num_features < 1)
+        return fail(MDK_ERR_ARG, "bad argument (windows=%d T=%d gpu_share=%d split_chunks=%d precision=%d)", windows, T, gpu_share, split_chunks, precision);
+    mdk_gru m;
+    m.desc = *desc;
+    m.D = desc->bidirectional ? 2 : 1;
+    m.precision = precision;
+    m.opt_gpu_share = gpu_share;
+    m.oor_seen = (mode & 4) != 0;
+    m.layers.resize((size_t)desc->num_layers);
+    m.layers[0].K = desc->num_features;
+    // (the fused layer-0 projection exists when the features + the bias row fit one 16-slot k-group: mdk_gru_create)
+    m.layers[0].wx_frag = desc->num_features + 1 <= 16 ? reinterpret_cast<half8 *>(sizeof(half8)) : nullptr;
+    static const float dummy = 0.f;
+    HostIO io;
+    if (host_io & 1) io.x_host = &dummy;
+    if (host_io & 2) io.p_host = const_cast<float *>(&dummy);
+    SplitPlan sp;
+    sp.S = split_chunks;
+    PassPlan P;
+    const int rc = plan_pass(&m, windows, T, (host_io & 3) ? &io : nullptr, split_chunks > 1 ? &sp : nullptr, P, (mode & 1) != 0, (mode & 2) != 0);
+    if (rc) return rc;
+    memset(out, 0, sizeof(*out));
+    out->windows_per_group = 4 * P.nq; out->work_groups = P.n_wg;
+    out->fuse_layer0 = P.fuse0; out->fuse_projection = P.fuse_proj; out->fuse_head = P.fuse_head; out->final_head = P.final_head;
+    out->overlap_gemm = P.overlap; out->stream_in = P.stream_in; out->stream_out = P.stream_out;
+    out->needs_gi = P.need_gi;
+    return MDK_OK;
+}
+
 extern "C" int mdk_split_plan(int B, int T, int gpu_share, int scan_split, int margin, mdk_split_shape *out) {
     if (!out) return fail(MDK_ERR_ARG, "null argument");
     if (B < 0 || T < 0 || gpu_share < 1 || gpu_share > 8 || scan_split < 0 || scan_split > kMaxSplit || margin < 16 || margin > 4096 || margin % 8)

@@ -32,6 +32,19 @@ def split_plan(B, T, gpu_share=1, scan_split=1, margin=128):
             "last": list(t.last)[:n]}
 
 
+def pass_plan(windows, T, num_features=10, num_layers=2, bidirectional=True, half=False, gpu_share=1, host_in=False,
+              host_out=False, split_chunks=0, host_checks_range=False, lean=False, out_of_range_seen=False):
+    """How a pass of `windows` windows of T columns would be launched (include/medaka_amd.h `mdk_pass_plan`; no device needed):
+    work-group granularity, what is fused / streamed, and whether the gi workspace is needed."""
+    desc = _lib.GruDesc(int(num_features), 128, int(num_layers), int(bool(bidirectional)), 5, 1)
+    t = _lib.PassShape()
+    mode = (1 if host_checks_range else 0) | (2 if lean else 0) | (4 if out_of_range_seen else 0)
+    _lib.check(_lib.load().mdk_pass_plan(ctypes.byref(desc), 1 if half else 0, int(gpu_share), int(windows), int(T),
+                                         (1 if host_in else 0) | (2 if host_out else 0), int(split_chunks), mode, ctypes.byref(t)),
+               "mdk_pass_plan")
+    return {n: (getattr(t, n) if n in ("windows_per_group", "work_groups") else bool(getattr(t, n))) for n, _ in t._fields_}
+
+
 class DeviceBuffer:
     """Raw device allocation through the C ABI (for hosts without a HIP binding of their own)."""
 

@@ -52,6 +52,12 @@ class SplitShape(ctypes.Structure):
                 ("start", ctypes.c_int * 16), ("first", ctypes.c_int * 16), ("last", ctypes.c_int * 16)]
 
 
+class PassShape(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "windows_per_group", "work_groups", "fuse_layer0", "fuse_projection", "fuse_head", "final_head",
+        "overlap_gemm", "stream_in", "stream_out", "needs_gi")]
+
+
 SPLIT_STATUS = {0: "not used", 1: "certified", 2: "rejected", 3: "disabled"}
 
 
@@ -72,6 +78,7 @@ ABI = {
     "mdk_gru_forward_staged": (_i, [_vp, ctypes.c_ulonglong, _i, _i, _vp]),
     "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
     "mdk_margin_sim": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "mdk_pass_plan": (_i, [ctypes.POINTER(GruDesc), _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(PassShape)]),
     "mdk_gru_device": (_i, [_vp]),
     "mdk_gru_destroy": (None, [_vp]),
     "mdk_rl_create": (_i, [ctypes.POINTER(RlDesc), ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(_vp)]),

@@ -94,6 +94,27 @@ def describe(model, desc, B, T):
     shape = lib.SplitShape()
     lib.check(lib.load().mdk_split_plan(B, T, 1, 1, 128, ctypes.byref(shape)), "mdk_split_plan")
     out["split_plan_at_margin_128"] = {"batch": B, "columns": T, "chunks": shape.chunks, "virtual_columns": shape.columns, "margin": shape.margin}
+    if name == "GRUModel" and out["engine_covers_it"]:
+        # how the passes of such a call are launched (mdk_pass_plan): the forward proper, and the audit's sequential scan
+        from medaka_amd import engine
+        kw = desc.get("kwargs") or {}
+        arch = dict(num_features=int(kw.get("num_features", 10)), num_layers=int(kw.get("n_layers", 2)),
+                    bidirectional=bool(kw.get("bidirectional", True)))
+        S = shape.chunks
+        try:
+            out["pass_plan"] = {
+                "forward": engine.pass_plan(S * B if S > 1 else B, shape.columns if S > 1 else T, split_chunks=S if S > 1 else 0,
+                                            host_checks_range=S > 1, host_out=True, host_in=S <= 1, **arch),
+                "audit_scan": engine.pass_plan(B, T, lean=True, host_checks_range=True, **arch) if S > 1 else None,
+            }
+            # (api.hip ensure_workspace: two activation buffers of D x 128 floats per column, the fused head's partial logits;
+            # gi = 3 x 128 floats per column and direction, only for passes that need it)
+            rows = -(-(S * B if S > 1 else B) // 8) * 8 * (shape.columns if S > 1 else T)
+            D, L = (2 if arch["bidirectional"] else 1), arch["num_layers"]
+            out["pass_plan"]["workspace_GB"] = round(rows * D * (512 * (2 if L > 1 else 1) + (20 if L > 1 else 0)) / 1e9, 2)
+            out["pass_plan"]["gi_GB_if_needed"] = round(rows * D * 1536 / 1e9, 2)
+        except RuntimeError as exc:            # e.g. more than 16 features: the exact variant only
+            out["pass_plan"] = {"error": str(exc)}
     return out
 
 

@@ -491,6 +491,9 @@ def test_validate_plan_only_on_a_state_dict_and_on_a_reference_archive(tmp_path,
     rep = validate.main([os.path.join(ROOT, "tests", "golden", "weights_trained.npz"), "--plan-only", "--batch", "100"])
     assert rep["model"]["class"] == "GRUModel" and rep["model"]["engine_covers_it"]
     assert rep["model"]["split_plan_at_margin_128"] == {"batch": 100, "columns": 10000, "chunks": 10, "virtual_columns": 1264, "margin": 128}
+    plan = rep["model"]["pass_plan"]           # how those passes are launched (mdk_pass_plan): the split call and its audit without gi
+    assert plan["forward"]["work_groups"] == 125 and plan["forward"]["fuse_projection"] and not plan["forward"]["needs_gi"]
+    assert plan["audit_scan"]["fuse_projection"] and not plan["audit_scan"]["needs_gi"] and plan["workspace_GB"] < 3.0
     ref_shim.install()
     import medaka.architectures as arch
     import medaka.models as ref_models
@@ -505,6 +508,7 @@ def test_validate_plan_only_on_a_state_dict_and_on_a_reference_archive(tmp_path,
         tar.add(top, arcname="model")
     rep = validate.main([str(tgz), "--plan-only", "--json", str(tmp_path / "r.json")])
     assert rep["model"]["source"] == "ModelStoreTGZ.load_model" and rep["model"]["class"] == "GRUModel" and rep["model"]["engine_covers_it"]
+    assert rep["model"]["pass_plan"]["forward"]["windows_per_group"] == 8
     assert json.load(open(tmp_path / "r.json"))["plan_only"]
     capsys.readouterr()
 
@@ -536,7 +540,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
     from medaka_amd import lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = {"mdk_gru_desc": lib.GruDesc, "mdk_rl_desc": lib.RlDesc, "mdk_rl_timing": lib.RlTiming,
-             "mdk_gru_timing": lib.GruTiming, "mdk_gru_split": lib.GruSplit, "mdk_split_shape": lib.SplitShape}
+             "mdk_gru_timing": lib.GruTiming, "mdk_gru_split": lib.GruSplit, "mdk_split_shape": lib.SplitShape,
+             "mdk_pass_shape": lib.PassShape}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "medaka_amd.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
