@@ -794,8 +794,14 @@ def main():
         step()                               # the model's first call: a split scan is audited against the sequential one
         torch.cuda.synchronize(dev)
         first_call = eng.split()
+    # `value` is taken at the margin the model STARTS at, whatever K and W are: the margin learner (option "scan_split_adapt": a
+    # smaller margin on trial after 8 quiet calls; a rejected trial costs its call a second forward, once) is held still during
+    # the timed region and let loose afterwards -- `value_at_learned_margin` is what a long run settles at
+    adapt_default = int(os.environ.get("MDK_SCAN_SPLIT_ADAPT", "8"))
+    eng.set_option("scan_split_adapt", 0)
     elapsed, mine = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev),
                                      steps=args.steps, warmup=args.warmup)
+    eng.set_option("scan_split_adapt", adapt_default)
     log(f'timed region done: {elapsed:.3f}s for {args.steps} steps')
     # keep only the timed steps' kernel records
     n_layers = len(eng.timing()["rec_ms"])
@@ -922,7 +928,9 @@ def main():
         "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
                            "(max_delta = largest |h_warm - h_carried|, threshold 2^-18; 2^-10 in half precision); the model's first call "
-                           "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp)"
+                           "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp); the "
+                           "margin is the one the model starts at -- its learner is held still during the timed steps (whatever K and "
+                           "W), `value_at_learned_margin` is where it settles"
                            if split["chunks"] > 1 else "sequential scan"),
         "sequential_scan": sequential,
         "host_to_host": {
