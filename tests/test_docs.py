@@ -79,3 +79,19 @@ def test_cited_sections_exist():
                 cites.add((s, m))
     bad = [(s, m) for s, m in sorted(cites) if m not in have]
     assert not bad, (bad, sorted(have))
+
+
+def test_cited_evidence_files_exist():
+    """Every `profiles/...` path the documents cite is a tracked file (or a glob / brace list that matches some)."""
+    import glob
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "r5_experiments", "README.md")):
+        text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
+        for m in re.finditer(r"profiles/[A-Za-z0-9_./{},*\-]+", text):
+            path = m.group(0).rstrip(".,)")
+            mm = re.match(r"(.*)\{([^}]*)\}(.*)", path)
+            for cand in ([mm.group(1) + x + mm.group(3) for x in mm.group(2).split(",")] if mm else [path]):
+                full = os.path.join(ROOT, cand)
+                if not (glob.glob(full) if "*" in cand else os.path.exists(full)):
+                    missing.append((doc, cand))
+    assert not missing, missing
