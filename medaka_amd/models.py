@@ -348,7 +348,7 @@ class LatentSpaceLSTM(ReadLevelFeaturesModel):
         self._engine_key = None
 
     def check_feature_encoder_compatibility(self, fenc):
-        """Check feature encoder is valid for this model (latent_space_lstm.py:209-240)."""
+        """Check feature encoder is valid for this model (latent_space_lstm.py:209-236)."""
         clsname = type(self).__name__
         if "ReadAlignmentFeatureEncoder" not in {c.__name__ for c in type(fenc).__mro__}:
             raise ValueError(f"{clsname} expects a ReadAlignmentFeatureEncoder.")
