@@ -89,6 +89,11 @@ def parse():
     ap.add_argument("--host-reps", type=int, default=7, help="timed host-to-host batches (median reported)")
     ap.add_argument("--extra-rl", type=float, default=15.0,
                     help="seconds of CPU baseline granted to the rl_lstm384 line that the default run appends under `extra` (0 = no extra line)")
+    ap.add_argument("--margin-256", type=int, default=0,
+                    help="1: also time 3 steps at a margin of 256 columns (`value_at_margin_256`: what a model with a longer memory runs at); "
+                         "off by default -- the larger workspace it allocates hands the old one back to the driver")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the complete record goes (stdout carries only the compact line the driver parses)")
     ap.add_argument("--loop-batches", type=int, default=14,
                     help="batches of the fed loop (threaded loader -> collate -> predict_on_batch -> writer; 0 = skip)")
     return ap.parse_args()
@@ -195,7 +200,7 @@ def reference_collate(samples):
     return Batch(counts_matrix=torch.stack([torch.from_numpy(s.features) for s in samples]).float())
 
 
-def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sample_workers=2, per_sample_submit=False):
+def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sample_workers=2, per_sample_submit=False, detail=False):
     """The engine inside the thread structure of the reference's inference loop (prediction.py:36-60, 225-370):
     `sample_workers` loader threads put Samples (views of a region's feature array, as `Sample.chunks` makes them)
     on a bounded queue, ONE Batcher thread groups `batch_size` of them and runs `collate`, the main thread calls
@@ -297,7 +302,9 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
             "predict_ms_median": statistics.median(predict_ms[warm:]),
             "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:]),
             "main_thread_hand_to_writer_ms_median": statistics.median(hand_ms[warm:]),
-            "writer_submits_per_batch": batch_size if per_sample_submit else 1}
+            "writer_submits_per_batch": batch_size if per_sample_submit else 1,
+            **({"predict_ms_all": [round(v, 3) for v in predict_ms], "wait_ms_all": [round(v, 3) for v in wait_ms],
+                "collate_ms_all": [round(v, 3) for v in collate_ms]} if detail else {})}
 
 
 def loop_windows(T, depth, seed, n_win=64):
@@ -338,7 +345,19 @@ MFMA_FLOP = 2 * 16 * 16 * 32        # one v_mfma_f32_16x16x32_f16
 SUSTAINED_MFMA_FRACTION = 0.66      # of the nominal issue rate over tens of seconds on this chip (profiles/probes/mfma_burn.hip: 0.64-0.67)
 
 
-def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families=None):
+def engine_plan(split, B, T, half):
+    """The work-group shape of the pass the timed steps ran, from the ENGINE's own planner (include/medaka_amd.h
+    `mdk_pass_plan`, device-free) -- not re-derived here: round 5's line priced half precision on 16-window groups the engine
+    no longer picks there."""
+    from medaka_amd import engine as _engine, models as _models
+    chunks = split["chunks"]
+    vwin = chunks * B if chunks > 1 else B
+    cols = split["columns"] if chunks > 1 else T
+    return _engine.pass_plan(vwin, cols, half=half, gpu_share=_models.gpu_share(), split_chunks=chunks if chunks > 1 else 0,
+                             host_checks_range=chunks > 1)
+
+
+def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families=None, plan=None):
     """One entry per hot kernel family of the consensus forward: milliseconds per step (hipEvents on the engine's streams),
     algorithmic FLOP (the network's own MACs on the REAL columns), issued FLOP (every MFMA the kernels execute: split
     products, the hi|lo row padding, the margin columns of a split scan), both as a fraction of the 2.5 PFLOP/s fp16 dense
@@ -346,10 +365,8 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
     rec0, rec1, gi, head, total = (statistics.mean(v) if v else 0.0 for v in timing_lists)
     cols = B * T
     vcols = split["chunks"] * B * split["columns"] if split["chunks"] > 1 else cols       # columns the kernels really scan
-    vwin = split["chunks"] * B if split["chunks"] > 1 else B
-    nq = 2 if (-(-vwin // 4)) * 2 > 232 else 1          # the engine's work-group rule (api.hip): 8-window groups once 4-window ones overflow the chip
-    if half:
-        nq = 1 if (-(-vwin // 4)) * 2 <= 232 else (2 if (-(-vwin // 8)) * 2 <= 232 else 4)
+    plan = plan or engine_plan(split, B, T, half)
+    nq = plan["windows_per_group"] // 4                 # windows per lane group: 4-, 8- or (half precision) 16-window work-groups
     wg_cols = vcols / (4.0 * nq) * 2                    # (work-group, step) pairs of one layer: both directions
     prod = 1 if half else 2                             # MFMAs per (k-step, gate): W_hi and W_lo passes (the hi|lo rows ride along)
     proj_prod = 1 if half else 3
@@ -386,7 +403,8 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
             "frac_issued_of_sustained_rate": issued_total / total / (PEAK_F16_DENSE_TFLOPS * SUSTAINED_MFMA_FRACTION) if total else None,
             "sustained_rate_note": f"a register-only MFMA loop on every SIMD sustains {SUSTAINED_MFMA_FRACTION:.2f} of the nominal rate over tens of "
                                    "seconds on this chip (power management; profiles/probes/mfma_burn.hip, profiles/r3_experiments/README.md)",
-            "virtual_columns_scanned": vcols, "real_columns": cols, "windows_per_work_group": 4 * nq}
+            "virtual_columns_scanned": vcols, "real_columns": cols, "windows_per_work_group": 4 * nq,
+            "work_groups_per_direction": plan["work_groups"]}
     if traffic_families:
         for e in k:
             for fam, rec in traffic_families.items():
@@ -484,7 +502,7 @@ def rl_kernel_entries(wide, B, P, D, front_ms, total_ms, half, front_tflops):
     ]
 
 
-def main_rl(args, emit=True):
+def main_rl(args, print_line=True):
     """BASELINE config 4b: the read-level model (reference LatentSpaceLSTM) over uint8 read matrices, one GPU
     per rank, input resident in HBM.  rl384 = the bundled rl_lstm384 architecture (lstm 384, 4 x uni-directional,
     dwells), weights from a seed (20 MB, not committed); rl128 = class defaults, committed trained-like weights."""
@@ -538,7 +556,7 @@ def main_rl(args, emit=True):
         "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
-                 "f32 (fp16 hi+lo split operands on the fp16 matrix pipe, fp32 accumulate)",
+                 "f32 (fp16 hi+lo split operands on the fp16 MFMA pipe, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"LatentSpaceLSTM({'lstm 384, 4 x uni-directional, dwells: rl_lstm384 architecture' if wide else 'lstm 128, bi-directional'}), "
                                f"batch {B} windows x {P} positions x {D} reads (uint8 read matrix), input resident in HBM",
@@ -600,8 +618,12 @@ def main_rl(args, emit=True):
             result["parity"] = {"max_abs_dp": float(np.abs(out - ref).max()),
                                 "argmax_identical": bool((out.argmax(-1) == ref.argmax(-1)).all()),
                                 "columns_checked": int(xs.shape[0] * xs.shape[1])}
-        if emit:
-            print(json.dumps(result), flush=True)
+        if print_line:
+            result["summary"] = {"unit": "M columns/s (ms)", "value": round(value / 1e6, 3), "ms_per_step": round(result["ms_per_step"], 2),
+                                 "metric_8d": round(result["host_to_host"]["value"] / 1e6, 3),
+                                 "parity_max_abs_dp": (result.get("parity") or {}).get("max_abs_dp"),
+                                 "cpu_baseline": (result.get("cpu_baseline") or {}).get("value")}
+            emit(result, args.full_out)
     ranks.close()
     return result if ranks.rank == 0 else None
 
@@ -622,9 +644,9 @@ def summary_of(result):
            "metric_8d": g(result, "metric_8d", "value", scale=M), "metric_8d_ms": g(result, "metric_8d", "ms_per_batch_median", nd=2),
            "first_calls_ms": g(result, "host_to_host", "first_calls_ms"),
            "fed_loop": g(result, "fed_loop", "value", scale=M), "pcie_diet": g(result, "pcie_diet_columns_per_s", scale=M),
+           "fed_loop_predict_ms": g(result, "fed_loop", "engine_collate", "predict_ms_median", nd=2),
            "sequential_scan": g(result, "sequential_scan", "value", scale=M),
-           "value_at_learned_margin": g(result, "value_at_learned_margin", "value", scale=M),
-           "value_at_margin_256": g(result, "value_at_margin_256", "value", scale=M),
+           "sequential_fed_loop": g(result, "sequential_fed_loop", "value", scale=M),
            "scan_split": {k: (float(f"{sp[k]:.3g}") if isinstance(sp.get(k), float) else sp.get(k)) for k in ("chunks", "margin", "status", "max_delta")},
            "roofline_frac": g(result, "roofline", "frac", nd=4), "roofline_frac_issued": g(result, "roofline", "frac_issued", nd=4),
            "parity_max_abs_dp": g(result, "parity", "max_abs_dp", nd=9), "cpu_baseline": g(result, "cpu_baseline", "value", scale=M, nd=4),
@@ -632,15 +654,100 @@ def summary_of(result):
     h = (result.get("extra") or {}).get("half") or {}
     if h:
         out["half"] = {"value": g(h, "value", scale=M), "ms_per_step": g(h, "ms_per_step", nd=3), "metric_8d": g(h, "metric_8d", "value", scale=M),
-                       "metric_8d_ms": g(h, "metric_8d", "ms_per_batch_median", nd=2),
-                       "fed_loop": g(h, "fed_loop", "value", scale=M), "max_abs_dp": g(h, "parity", "max_abs_dp", nd=9),
+                       "metric_8d_ms": g(h, "metric_8d", "ms_per_batch_median", nd=2), "first_calls_ms": g(h, "metric_8d", "first_calls_ms"),
+                       "fed_loop": g(h, "fed_loop", "value", scale=M), "fed_loop_predict_ms": g(h, "fed_loop", "predict_ms_median", nd=2),
+                       "sequential_fed_loop": g(h, "sequential_fed_loop", "value", scale=M),
+                       "margin": g(h, "scan_split", "margin"), "max_abs_dp": g(h, "parity", "max_abs_dp", nd=9),
                        "argmax_identical_columns": g(h, "parity", "argmax_identical_columns"), "columns_checked": g(h, "parity", "columns_checked"),
-                       "split": g(h, "scan_split", "status"), "roofline_frac": g(h, "roofline", "frac", nd=4), "error": h.get("error")}
+                       "split": g(h, "scan_split", "status"), "roofline_frac": g(h, "roofline", "frac", nd=4),
+                       "roofline_frac_issued": g(h, "roofline", "frac_issued", nd=4), "error": h.get("error")}
     r = (result.get("extra") or {}).get("rl384") or {}
     if r:
         out["rl384"] = {"value": g(r, "value", scale=M, nd=3), "ms_per_step": g(r, "ms_per_step", nd=2),
                         "metric_8d": g(r, "host_to_host", "value", scale=M, nd=3), "parity": g(r, "parity", "max_abs_dp", nd=9), "error": r.get("error")}
     return out
+
+
+LINE_BUDGET = 6144          # bytes of the ONE stdout line (round 5's grew to 20.8 KB and the driver's record came back unparsed)
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "cpu_baseline", "summary")
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_issued", "traffic", "avg_launch_ms", "launches_timed",
+                 "algorithmic_flop_per_launch", "peak_note")
+CPU_KEYS = ("value", "unit", "cores", "kind", "passes", "sample")
+
+
+def _clip(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1].rstrip() + "~"
+
+
+def _finite(o):
+    """NaN / infinity -> None, recursively: the line must survive a strict JSON parser."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def compact_line(result):
+    """The ONE line of stdout: exactly the keys the driver keeps, strings clipped, `summary` last, <= LINE_BUDGET bytes by
+    construction (tests/test_bench_line_cpu.py).  Everything else the run measured -- `extra`, `fed_loop`, the per-kernel table,
+    every `what` / `note` -- goes to the side file (`--full-out`, default bench_full.json beside this script) and to stderr."""
+    roof = result.get("roofline") or {}
+    cpu = result.get("cpu_baseline") or {}
+    cfg = {k: _clip(v, 150 if k == "workload" else 90) for k, v in (result.get("config") or {}).items()}
+    line = {k: result.get(k) for k in LINE_KEYS[:10]}
+    line["dtype"] = _clip(result.get("dtype"), 80)
+    line["data"] = _clip(result.get("data"), 40)
+    line["config"] = cfg
+    line["roofline"] = {k: _clip(roof.get(k), 100 if k == "kernel" else 80) for k in ROOFLINE_KEYS} if roof else None
+    line["cpu_baseline"] = {k: _clip(cpu.get(k), 120) for k in CPU_KEYS} if cpu else None
+    line["summary"] = result.get("summary")
+    line = _finite(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_BUDGET:            # cannot happen with the caps above unless `summary` outgrew its own: shed it piece by piece
+        for k in ("rl384", "half", "first_calls_ms"):
+            (line.get("summary") or {}).pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) <= LINE_BUDGET:
+                break
+    assert len(text) <= LINE_BUDGET, len(text)
+    return text
+
+
+def emit(result, full_out):
+    """stdout: the compact line (and nothing else); the side file and stderr: everything."""
+    full = json.dumps(_finite(result), allow_nan=False)
+    try:
+        with open(full_out, "w") as f:
+            f.write(full + "\n")
+    except OSError as exc:
+        log(f"could not write {full_out}: {exc}")
+    print(full, file=sys.stderr, flush=True)
+    print(compact_line(result), flush=True)
+
+
+def settle_margin(eng, step, max_calls=72):
+    """Untimed calls until the split scan's margin learner (include/medaka_amd.h "scan_split_adapt") has stopped moving, so that
+    the timed region measures the DEFAULT configuration in its steady state -- learner on, no trial left to run: a smaller
+    margin is tried after `adapt` quiet certified calls and a rejected trial costs its call a second forward, once.  Settled =
+    `adapt` + 2 calls in a row at one margin without a rejection.  Returns the margins the calls were answered at."""
+    adapt = int(os.environ.get("MDK_SCAN_SPLIT_ADAPT", "8"))
+    seen, same, last = [], 0, None
+    for _ in range(max_calls):
+        step()
+        sp = eng.split()
+        if sp["chunks"] <= 1:
+            break
+        key = (sp["margin"], sp["fallbacks"], sp["status"])
+        same = same + 1 if key == last else 0
+        last = key
+        seen.append(sp["margin"])
+        if adapt == 0 or same >= adapt + 2:
+            break
+    return seen
 
 
 def half_section(args, ref_probs):
@@ -659,20 +766,21 @@ def half_section(args, ref_probs):
             ref = os.path.join(tmp, "ref.npy")
             np.save(ref, ref_probs)
             cmd += ["--parity-ref", ref]
+        full = os.path.join(tmp, "half_full.json")
+        cmd += ["--full-out", full]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        raise RuntimeError(f"child bench --half failed (rc {r.returncode}): {r.stderr[-400:]}")
-    h = json.loads(lines[-1])
+        if r.returncode != 0 or not os.path.exists(full):
+            raise RuntimeError(f"child bench --half failed (rc {r.returncode}): {r.stderr[-400:]}")
+        h = json.load(open(full))
     roof = h.get("roofline") or {}
     res = {"what": "model.half() -- the reference CLI's GPU default (prediction.py:164-168): `bench.py --half` on the same batch in a child "
                    "process, same definitions as the line above (fp16 operands, fp32 accumulate, one product: k_rec_fused<HP>)",
            "value": h["value"], "unit": h["unit"], "ms_per_step": h["ms_per_step"], "steps": h["steps"], "warmup": h["warmup"], "dtype": h["dtype"],
            "scan_split": {k: h["scan_split"].get(k) for k in ("chunks", "columns", "margin", "status", "max_delta", "fallbacks",
-                                                              "first_call_audited", "first_call_audit_max_dp")},
+                                                              "first_call_audited", "first_call_audit_max_dp", "margins_seen")},
            "metric_8d": {k: h["host_to_host"].get(k) for k in ("value", "unit", "ms_per_batch_median", "timed_batches", "first_calls_ms",
                                                                "frac_of_device_resident", "one_copy_each_way_ms_per_batch")},
-           "sequential_scan": h.get("sequential_scan"), "value_at_learned_margin": h.get("value_at_learned_margin"),
+           "sequential_scan": h.get("sequential_scan"), "sequential_fed_loop": h.get("sequential_fed_loop"),
            "fed_loop": ({"value": h["fed_loop"]["value"], **{k: h["fed_loop"]["engine_collate"].get(k) for k in
                                                              ("ms_per_batch", "predict_ms_median", "collate_ms_median", "timed_batches")}}
                         if h.get("fed_loop") else None),
@@ -794,14 +902,14 @@ def main():
         step()                               # the model's first call: a split scan is audited against the sequential one
         torch.cuda.synchronize(dev)
         first_call = eng.split()
-    # `value` is taken at the margin the model STARTS at, whatever K and W are: the margin learner (option "scan_split_adapt": a
-    # smaller margin on trial after 8 quiet calls; a rejected trial costs its call a second forward, once) is held still during
-    # the timed region and let loose afterwards -- `value_at_learned_margin` is what a long run settles at
-    adapt_default = int(os.environ.get("MDK_SCAN_SPLIT_ADAPT", "8"))
-    eng.set_option("scan_split_adapt", 0)
+    # `value` is the DEFAULT configuration in its steady state (round 5 held the margin learner still for the timed
+    # steps): the learner (option "scan_split_adapt": a smaller margin on trial after 8 quiet certified calls; a rejected trial
+    # costs its call a second forward, once) is left ON, and run to where it stops moving in untimed calls first
+    margins_seen = [first_call.get("margin")] if not args.device_only else []
+    if not args.device_only and args.scan_split is None and args.scan_split_margin is None:
+        margins_seen += settle_margin(eng, lambda: (step(), torch.cuda.synchronize(dev)))
     elapsed, mine = dist.timed_steps(ranks, step_timed, lambda: torch.cuda.synchronize(dev),
                                      steps=args.steps, warmup=args.warmup)
-    eng.set_option("scan_split_adapt", adapt_default)
     log(f'timed region done: {elapsed:.3f}s for {args.steps} steps')
     # keep only the timed steps' kernel records
     n_layers = len(eng.timing()["rec_ms"])
@@ -812,47 +920,12 @@ def main():
     split["ranks_certified"] = int(ranks.sum_over_ranks(1.0 if split["status"] == "certified" else 0.0))     # (every rank splits its own batch)
     split["first_call_audited"] = first_call["audited"]          # (one extra, untimed call before the warm-up steps)
     split["first_call_audit_max_dp"] = first_call["audit_max_dp"]
-    sequential = None
-    if split["chunks"] > 1 and not args.device_only:
-        # the same steps as the plain sequential scan, for the record (not `value`): 3 steps after 1 warm-up
-        eng.set_option("scan_split", 0)
-        seq_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
-        eng.set_option("scan_split", args.scan_split if args.scan_split is not None else 1)
-        sequential = {"value": ranks.world * cols_per_step * 3 / seq_elapsed, "unit": "pileup columns/s",
-                      "ms_per_step": 1e3 * seq_elapsed / 3, "steps": 3}
-
-    learned = None
-    if split["chunks"] > 1 and not args.device_only and args.scan_split is None and args.scan_split_margin is None:
-        # the margin is learned per model (include/medaka_amd.h "scan_split_adapt"): let the engine finish learning here, outside
-        # every timed region -- a smaller margin on trial that is rejected costs its call a second forward -- then time 3 steps
-        seen = [split["margin"]]
-        for _ in range(24):
-            step()
-            seen.append(eng.split()["margin"])
-        torch.cuda.synchronize(dev)
-        l_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
-        l_split = eng.split()
-        learned = {"value": ranks.world * cols_per_step * 3 / l_elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * l_elapsed / 3, "steps": 3,
-                   "margin": l_split["margin"], "chunks": l_split["chunks"], "columns": l_split["columns"], "status": l_split["status"],
-                   "margins_tried": sorted(set(seen), reverse=True), "rejected_trials": l_split["fallbacks"] - split["fallbacks"],
-                   "what": "after 24 more calls: the margin this model settles at (a rung of 64 .. 512 down while the junction differences sit "
-                           "at the noise floor, a rejected trial goes back for good); the weights of this line need 128"}
-    at_margin_256 = None
-    if split["chunks"] > 1 and not args.device_only and (args.scan_split_margin or 128) < 256:
-        # what a model that needs twice the default margin would run at (the margin is the split scan's price)
-        eng.set_option("scan_split_margin", 256)
-        m_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
-        m_split = eng.split()
-        eng.set_option("scan_split_margin", args.scan_split_margin or 128)
-        step(); torch.cuda.synchronize(dev)                # (back at the default margin; its first call is audited again)
-        at_margin_256 = {"value": ranks.world * cols_per_step * 3 / m_elapsed, "unit": "pileup columns/s", "ms_per_step": 1e3 * m_elapsed / 3,
-                         "steps": 3, "chunks": m_split["chunks"], "columns": m_split["columns"], "status": m_split["status"]}
     if args.device_only:
         if ranks.rank == 0:
             print(json.dumps({"metric": "pileup columns/sec (consensus bi-GRU inference)", "value": value,
                               "unit": "pileup columns/s", "n_gpus": ranks.world, "steps": args.steps,
                               "ms_per_step": 1e3 * elapsed / args.steps, "device_only": True, "batch_windows": B,
-                              "scan_split": split, "sequential": sequential,
+                              "scan_split": split,
                               "rec_ms_per_step": sum(rec_ms) / args.steps,
                               "rec_l0_ms": statistics.mean(rec_l0[-args.steps:]), "rec_l1_ms": statistics.mean(rec_l1[-args.steps:]),
                               "gi_ms_per_step": statistics.mean(gi_ms[-args.steps:]),
@@ -915,7 +988,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
-                 "f32 (fp16 hi+lo split operands on the fp16 matrix pipe, fp32 accumulate; <= 1e-6 of fp32)",
+                 "f32 (fp16 hi+lo split operands on the fp16 MFMA pipe, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"r1041_e82_400bps_sup-architecture consensus (GRUModel 10->2x biGRU128->5), "
                                f"synthetic {args.depth}x pileup windows, batch {B} x {T} columns per GPU, "
@@ -929,10 +1002,10 @@ def main():
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
                            "(max_delta = largest |h_warm - h_carried|, threshold 2^-18; 2^-10 in half precision); the model's first call "
                            "was also run as the sequential scan on the device and compared in full (first_call_audit_max_dp); the "
-                           "margin is the one the model starts at -- its learner is held still during the timed steps (whatever K and "
-                           "W), `value_at_learned_margin` is where it settles"
-                           if split["chunks"] > 1 else "sequential scan"),
-        "sequential_scan": sequential,
+                           "margin is the one the model's learner SETTLED at in untimed calls before the timed region (`margins_seen`; "
+                           "option \"scan_split_adapt\" left at its default: the timed steps are the default configuration)"
+                           if split["chunks"] > 1 else "sequential scan",
+                           margins_seen=margins_seen),
         "host_to_host": {
             "value": ranks.world * cols_per_step / h_med, "unit": "pileup columns/s",
             "ms_per_batch_median": 1e3 * h_med, "timed_batches": n_h2h, "warmup": 2 + settle, "settle_seconds": settle_s,
@@ -960,10 +1033,6 @@ def main():
                                    "PCIe-inclusive rate out of it; neither BASELINE.json nor SURVEY.md says that, SURVEY 8d asks for THIS figure"}
     result["value_basis"] = "device-resident (inputs in HBM at the start of the timed region); SURVEY 8d's host-to-host rate is `metric_8d`"
 
-    if learned:
-        result["value_at_learned_margin"] = learned
-    if at_margin_256:
-        result["value_at_margin_256"] = at_margin_256
     shared_loop = None
     ref_probs = None
     if args.shared_gpu and ranks.world > 1 and args.loop_batches > 2:
@@ -1057,6 +1126,38 @@ def main():
             out_holder["diet"] = model.predict_on_counts(cnt, dep, decoded=True)
             diet.append(time.perf_counter() - t0)
         result["pcie_diet_columns_per_s"] = cols_per_step / statistics.median(diet[3:])
+    # Sections that re-arm the margin learner (setting "scan_split" does) or make the workspace grow (a larger margin: the old
+    # activations are handed back to the driver, which wipes them on the DMA engines -- behind which the host path's strided
+    # copies wait) come LAST: in round 5 they sat in front of the host-path sections, and the half line's
+    # first hundred host-to-host calls ran at 8.6 ms instead of 5.6.
+    if split["chunks"] > 1:
+        # the same steps as the plain sequential scan, for the record (not `value`): 3 steps after 1 warm-up
+        eng.set_option("scan_split", 0)
+        seq_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
+        result["sequential_scan"] = {"value": ranks.world * cols_per_step * 3 / seq_elapsed, "unit": "pileup columns/s",
+                                     "ms_per_step": 1e3 * seq_elapsed / 3, "steps": 3}
+        if args.loop_batches > 2 and ranks.world == 1:
+            # ... and the fed loop on sequential scans: what a model whose certificate is rejected (one that latches state) runs at
+            from medaka_amd import torch_ext
+            windows = loop_windows(T, args.depth, 4321)
+            fast = lambda data: torch_ext.Batch.collate(data)
+            fed_loop(model, windows, B, 3, fast, warm=1)
+            sl = fed_loop(model, windows, B, max(8, args.loop_batches // 2), fast)
+            result["sequential_fed_loop"] = {k: sl[k] for k in ("value", "unit", "ms_per_batch", "timed_batches", "predict_ms_median",
+                                                                "main_thread_cycle_ms_median", "steady_state_value")}
+            log(f"fed loop on sequential scans: {sl['value'] / 1e6:.1f} M columns/s, predict {sl['predict_ms_median']:.2f} ms per batch")
+        eng.set_option("scan_split", args.scan_split if args.scan_split is not None else 1)
+        if args.margin_256 and (args.scan_split_margin or 128) < 256:
+            # what a model that needs twice the default margin would run at (the margin is the split scan's price)
+            eng.set_option("scan_split_adapt", 0)
+            eng.set_option("scan_split_margin", 256)
+            m_elapsed, _ = dist.timed_steps(ranks, step, lambda: torch.cuda.synchronize(dev), steps=3, warmup=1)
+            m_split = eng.split()
+            eng.set_option("scan_split_margin", args.scan_split_margin or 128)
+            eng.set_option("scan_split_adapt", int(os.environ.get("MDK_SCAN_SPLIT_ADAPT", "8")))
+            result["value_at_margin_256"] = {"value": ranks.world * cols_per_step * 3 / m_elapsed, "unit": "pileup columns/s",
+                                             "ms_per_step": 1e3 * m_elapsed / 3, "steps": 3, "chunks": m_split["chunks"],
+                                             "columns": m_split["columns"], "status": m_split["status"]}
     if ranks.world == 1 and not args.shared_gpu and not args.half and args.extra_half:
         # the precision `medaka inference` selects on a GPU by default, on the same line (reference prediction.py:164-168)
         try:
@@ -1071,12 +1172,12 @@ def main():
         del model, eng
         torch.cuda.empty_cache()
         try:
-            result.setdefault("extra", {})["rl384"] = main_rl(a2, emit=False)
+            result.setdefault("extra", {})["rl384"] = main_rl(a2, print_line=False)
         except Exception as exc:                      # the headline line must not depend on it
             result.setdefault("extra", {})["rl384"] = {"error": f"{type(exc).__name__}: {exc}"}
     if ranks.rank == 0:
         result["summary"] = summary_of(result)        # LAST key: whoever keeps only the tail of this line keeps the figures
-        print(json.dumps(result), flush=True)
+        emit(result, args.full_out)
     ranks.close()
 
 
