@@ -172,12 +172,12 @@ def cpu_baseline(weights_path, x_host, probs_sample, budget_s):
             "host_cores_available": cores, "os_cpu_count": os.cpu_count(), "table": table, "not_run": skipped,
             "wall_clock_cap_s": budget_s,
             "passes": best["passes"],
-            "sample": f"{best['passes']} timed pass(es) (median) after a warm-up of B={best['batch']} x {T} columns on {best['threads']} torch threads "
-                      f"(the box shows os.cpu_count() = {os.cpu_count()}, {cores} usable), fp32 PyTorch-CPU: the best cell of the BASELINE.md "
-                      f"section-4 grid that fits {budget_s:.0f} s of wall clock; kind = "
-                      + ("reference: the unmodified reference GRUModel.predict_on_batch (/root/reference present)" if kind == "reference" else
-                         "port: the three torch calls of reference gru.py:66-71 restated (nn.GRU + Linear + softmax; /root/reference does not "
-                         "exist on the GPU box)")}
+            "sample": f"B={best['batch']} x {T}, {best['threads']} torch threads, fp32 PyTorch-CPU, {best['passes']} pass(es) + warm-up; best cell "
+                      f"of BASELINE.md s4 grid in {budget_s:.0f} s",
+            "sample_note": f"the box shows os.cpu_count() = {os.cpu_count()}, {cores} usable; kind = "
+                           + ("reference: the unmodified reference GRUModel.predict_on_batch (/root/reference present)" if kind == "reference" else
+                              "port: the three torch calls of reference gru.py:66-71 restated (nn.GRU + Linear + softmax; /root/reference does not "
+                              "exist on the GPU box)")}
     n = ref.shape[0]
     parity = {"max_abs_dp": float(np.abs(probs_sample[:n] - ref).max()),
               "argmax_identical": bool((probs_sample[:n].argmax(-1) == ref.argmax(-1)).all()),
@@ -990,14 +990,13 @@ def main():
         "dtype": "f16 (fp16 operands, fp32 accumulate)" if args.half else
                  "f32 (fp16 hi+lo split operands on the fp16 MFMA pipe, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"r1041_e82_400bps_sup-architecture consensus (GRUModel 10->2x biGRU128->5), "
-                               f"synthetic {args.depth}x pileup windows, batch {B} x {T} columns per GPU, "
-                               f"input resident in HBM, probabilities left in HBM",
+        "config": {"workload": f"r1041_e82_400bps_sup-architecture consensus (GRUModel 10->2x biGRU128->5), synthetic {args.depth}x pileup, "
+                               f"batch {B} x {T} per GPU, x and probabilities in HBM",
                    "batch_windows": B, "chunk_len": T, "columns_per_step_per_gpu": cols_per_step,
-                   "weights": "tests/golden/weights_trained.npz (reference-trained on synthetic data; "
-                              "published model archives are git-LFS stubs offline)",
+                   "weights": "tests/golden/weights_trained.npz (reference-trained, synthetic data)",
+                   "weights_note": "published model archives are git-LFS stubs offline",
                    "parallelism": f"{ranks.world} independent replicas, window-sharded, no collective"
-                                  + (" -- DRY CHECK: all ranks share device 0, not a scaling measurement" if args.shared_gpu else "")},
+                                  + (" (DRY CHECK: ranks share device 0)" if args.shared_gpu else "")},
         "scan_split": dict(split, what="chunks per window of the timed steps (include/medaka_amd.h \"scan_split\"): the batch ran as "
                            f"{split['chunks'] * B} windows of {split['columns']} columns; every junction certified on the device "
                            "(max_delta = largest |h_warm - h_carried|, threshold 2^-18; 2^-10 in half precision); the model's first call "
@@ -1073,13 +1072,15 @@ def main():
         if traffic_doc:
             dom_traffic = traffic_doc.get("k_rec_fused_bytes_per_step") if "k_rec_fused" in dom["kernel"] else traffic_doc.get("k_rec_mfma_bytes_per_launch")
         result["roofline"] = {
-            "kernel": dom["kernel"] + (" -- one layer pass over all (virtual) windows, both directions, every step = TWO launches of the kernel: "
-                                       "steps [0, T/2) with HEAD = 1 (partial logits), [T/2, T) with HEAD = 2 (probabilities); "
-                                       "`avg_launch_ms` / `algorithmic_flop_per_launch` are those of the pair, each launch has half of both"
-                                       if fused_flags[0] & 512 else
-                                       " -- one launch = one layer pass over all (virtual) windows, both directions, every step")
-                      + ("" if split["chunks"] == 1 else f"; the split scan runs {split['chunks'] * B} windows of {split['columns']} columns, the "
-                         "algorithmic FLOP are those of the REAL columns (margins are overhead)"),
+            "kernel": ("k_rec_fused: layer 1 = K=256 projection + recurrence + Linear + softmax; HEAD=1 + HEAD=2 launch pair"
+                       if fused_flags[0] & 512 else dom["kernel"].split(" (")[0] + ": one launch = one layer pass, both directions"),
+            "kernel_note": dom["kernel"] + (" -- one layer pass over all (virtual) windows, both directions, every step = TWO launches of the kernel: "
+                                            "steps [0, T/2) with HEAD = 1 (partial logits), [T/2, T) with HEAD = 2 (probabilities); "
+                                            "`avg_launch_ms` / `algorithmic_flop_per_launch` are those of the pair, each launch has half of both"
+                                            if fused_flags[0] & 512 else
+                                            " -- one launch = one layer pass over all (virtual) windows, both directions, every step")
+                           + ("" if split["chunks"] == 1 else f"; the split scan runs {split['chunks'] * B} windows of {split['columns']} columns, the "
+                              "algorithmic FLOP are those of the REAL columns (margins are overhead)"),
             "bound": "mfma", "achieved": dom["algorithmic_tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": dom["algorithmic_tflops"] / peak, "traffic": dom_traffic,
             "frac_issued": dom["frac_issued_of_fp16_peak"],
@@ -1089,8 +1090,8 @@ def main():
                     "fp16 hi+lo operands: 3 products in the projection, 4 in the recurrence); `frac_issued` counts every MFMA the kernel "
                     f"executes (row padding, margin columns) against the undivided {PEAK_F16_DENSE_TFLOPS:.0f}; a native fp32-MFMA kernel would be capped at "
                     f"{PEAK_F32_MATRIX_TFLOPS} TFLOP/s, of which this launch reaches {dom['algorithmic_tflops'] / PEAK_F32_MATRIX_TFLOPS:.2f}",
-            "peak_note": f"{peak:.0f} TF = {PEAK_F16_DENSE_TFLOPS / 1000:.1f} PF fp16 dense MFMA / {issue_factor:.2f} (fp16 MACs issued per algorithmic MAC for fp32 parity); "
-                         "not a hardware number -- `frac_issued` is against the undivided hardware peak",
+            "peak_note": (f"{peak:.0f} TF = 2.5 PF fp16 dense MFMA (hardware peak)" if args.half else
+                          f"{peak:.0f} TF = 2.5 PF fp16 dense / {issue_factor:.2f} fp16 MACs per MAC (fp32 parity); not a hw peak"),
             "frac_of_f32_matrix_peak": dom["algorithmic_tflops"] / PEAK_F32_MATRIX_TFLOPS,
             "kernels": kernels, "step": step_level,
             "pmc": pmc_summary_r4() if (B == 200 and T == 10000 and not args.half and split["chunks"] > 1 and fused1) else None,

@@ -703,7 +703,11 @@ static int plan_pass(const mdk_gru *m, int nb, int T, const HostIO *io, const Sp
     // GEMM under): the projection runs INSIDE the recurrence kernel, strip by strip, and gi never exists in HBM
     // (rec_fused.hpp; bit-identical to the GEMM + recurrence pair).  fp32-parity or half mode, 8-window work-groups, T a
     // multiple of the strip.  "fuse_proj" = 2 prefers it to the side-stream GEMM as well.
-    P.fuse_proj = L >= 2 && nq == 2 && !P.ablated && T % kFusedSteps == 0 &&
+    // (rec_fused.hpp addresses a tile's activations through a buffer resource: 32-bit byte offsets t * D * 4096 inside a 2 GB
+    // window -- beyond T * D * 4096 = 2^31 the offsets would wrap, loads return 0 and stores are dropped: such a scan takes the
+    // GEMM + k_rec_mfma pair, whose addresses are 64-bit)
+    const bool fused_addressable = (long long)T * D * 4096 < (1LL << 31);
+    P.fuse_proj = L >= 2 && nq == 2 && !P.ablated && T % kFusedSteps == 0 && fused_addressable &&
                   (m->opt_fuse_proj == 2 || (m->opt_fuse_proj == 1 && (lean || P.n_wg * D * m->opt_gpu_share > kOvMaxWgs)));   // auto: the recurrence fills the chip
     P.overlap = overlap_ok && !P.fuse_proj;
     // ... and with it the classifier's Linear (rec_fused.hpp HEAD): the last layer leaves partial logits, k_head_combine

@@ -34,19 +34,29 @@ class Ranks:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            if backend not in ("nccl", "gloo"):
+                raise ValueError(f"medaka_amd.dist.Ranks: backend {backend!r} is not supported (\"nccl\" = RCCL, \"gloo\", or None to choose)")
+            if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+                # a launcher that isolates the ranks (HIP_VISIBLE_DEVICES per rank) shows each of them ONE device, index 0
+                self.device_index = self.local_rank if self.local_rank < torch.cuda.device_count() else 0
             if dist.is_initialized():
+                # somebody else's group: use it as it is -- on the device this rank can really see
                 self.backend = dist.get_backend()
+                if self.backend == "nccl" and torch.cuda.is_available():
+                    torch.cuda.set_device(self.device_index)
                 return
-            # the ranks' own store: agreement on the backend must not depend on the backend
-            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 17, self.world, is_master=(self.rank == 0),
+            # the ranks' own store: agreement on the backend must not depend on the backend.  Its port: MEDAKA_AMD_STORE_PORT, else
+            # MASTER_PORT + 17 folded back into the unprivileged range (a MASTER_PORT near 65535 must not produce an invalid port,
+            # on which every rank would wait out the 300 s store time-out)
+            port = os.environ.get("MEDAKA_AMD_STORE_PORT")
+            port = int(port) if port else 1024 + (int(os.environ["MASTER_PORT"]) + 17 - 1024) % (65536 - 1024)
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], port, self.world, is_master=(self.rank == 0),
                                   timeout=datetime.timedelta(seconds=300), wait_for_workers=True)
             if backend == "nccl":
                 err = None
                 try:
                     if not torch.cuda.is_available() or torch.cuda.device_count() == 0:
                         raise RuntimeError(f"rank {self.rank}: no HIP device {self.local_rank} (device_count = {torch.cuda.device_count()})")
-                    # a launcher that isolates the ranks (HIP_VISIBLE_DEVICES per rank) shows each of them ONE device, index 0
-                    self.device_index = self.local_rank if self.local_rank < torch.cuda.device_count() else 0
                     torch.cuda.set_device(self.device_index)
                 except Exception as exc:               # noqa: BLE001 -- whatever it is, this rank cannot take part in RCCL
                     err = f"{type(exc).__name__}: {exc}"

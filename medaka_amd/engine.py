@@ -262,8 +262,10 @@ class GruEngine:
     def close(self):
         # a Batcher thread may be inside stage_input: no hand-over targets this engine any more, and the handle is only
         # destroyed once that call has returned
-        from medaka_amd import torch_ext as _te
-        _te.forget_stage_target(self)
+        import sys
+        te = sys.modules.get("medaka_amd.torch_ext")       # (imports torch: only there if somebody registered a hand-over target)
+        if te is not None:
+            te.forget_stage_target(self)
         with self._stage_lock:
             h, self._h = self._h, ctypes.c_void_p()
         if h:

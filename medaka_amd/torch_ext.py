@@ -56,12 +56,13 @@ def forget_stage_target(engine):
 
 
 def _stage(out):
-    if _stage_target is None or os.environ.get("MEDAKA_AMD_STAGE", "1") == "0" or not out.is_pinned():
-        return
-    eng = _stage_target()
-    if eng is None or out.dim() != 3 or out.shape[2] != eng.num_features:
+    ref = _stage_target               # read ONCE: close() on the main thread may clear the global under this (Batcher) thread
+    if ref is None or os.environ.get("MEDAKA_AMD_STAGE", "1") == "0" or not out.is_pinned():
         return
     try:
+        eng = ref()
+        if eng is None or out.dim() != 3 or out.shape[2] != eng.num_features:
+            return
         tok = eng.stage_input(out.data_ptr(), out.shape[0], out.shape[1])
         if tok:
             # what was copied: this tensor, these bytes.  `predict_on_batch` redeems the token only if the tensor is still the

@@ -74,3 +74,18 @@ def test_wide_inputs_and_bad_arguments():
     for kw in (dict(windows=0, T=10), dict(windows=1, T=0), dict(windows=1, T=10, gpu_share=9), dict(windows=1, T=10, split_chunks=99)):
         with pytest.raises(RuntimeError):
             engine.pass_plan(**kw)
+
+
+def test_the_fused_kernel_is_not_planned_beyond_its_32_bit_offsets():
+    """rec_fused.hpp addresses a tile through 32-bit byte offsets t * D * 4096 in a 2 GB buffer window: at T * D * 4096 >= 2^31
+    (T >= 262144 bidirectional) loads would return 0 and stores be dropped -- also in an audit's `lean` scan of a few very
+    long windows, whose result would then be delivered as "the sequential one" (ADVICE r5).  Such scans take the unfused pair."""
+    edge = (1 << 31) // (2 * 4096)                                              # 262144
+    for kw in (dict(lean=True, host_checks_range=True), dict()):
+        below = engine.pass_plan(8 if kw else 1000, edge - 16, **kw)
+        above = engine.pass_plan(8 if kw else 1000, edge, **kw)
+        assert below["fuse_projection"] and below["final_head"], (kw, below)
+        assert not above["fuse_projection"] and not above["final_head"] and above["needs_gi"], (kw, above)
+    # one-directional models have half the column stride
+    assert engine.pass_plan(8, edge, bidirectional=False, lean=True, host_checks_range=True)["fuse_projection"]
+    assert not engine.pass_plan(8, 2 * edge, bidirectional=False, lean=True, host_checks_range=True)["fuse_projection"]
