@@ -265,17 +265,23 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("MDK_SCAN_SPLIT", None)
     common = ["--steps", "3", "--warmup", "1", "--cpu-budget", "0", "--loop-batches", "0", "--host-reps", "3", "--extra-rl", "0"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shared-gpu"] + common,
+    # (stdout carries the compact driver line only; everything else the run measured is in the side file)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shared-gpu", "--full-out", str(tmp_path / "one.json")] + common,
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
-    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = json.load(open(tmp_path / "one.json"))
+    assert l1["value"] == r1["value"] and l1["roofline"]["frac"] == r1["roofline"]["frac"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29677", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu"] + common,
+                          "--master-port", "29677", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--full-out", str(tmp_path / "two.json")] + common,
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-3000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines                                  # rank 0 alone reports
-    r2 = json.loads(lines[0])
+    l2 = json.loads(lines[0])
+    assert len(lines[0]) <= 6144 and l2["n_gpus"] == 2 and l2["roofline"] and "cpu_baseline" in l2
+    r2 = json.load(open(tmp_path / "two.json"))
+    assert l2["value"] == r2["value"]
     assert r2["n_gpus"] == 2 and r2["scaling"] == "weak" and r2["steps"] == 3
     assert r2["scan_split"]["ranks_certified"] == 2 and r2["scan_split"]["chunks"] >= 2, r2["scan_split"]
     ratio = r2["value"] / r1["value"]
