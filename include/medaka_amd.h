@@ -94,6 +94,8 @@ typedef struct {
     int audits;           /* audited calls since the model was created (first calls + every "scan_split_audit_every"-th) */
     int audit_failures;   /* ... of which found a difference above the audit tolerance (the split is then turned off) */
     float audit_worst_dp; /* largest |p_split - p_sequential| any audit has seen */
+    int probes;           /* half precision: calls that were also run once in fp32-parity mode to certify the margin ("scan_split_probe") */
+    float probe_max_delta; /* largest junction difference of the last such probe (threshold 2^-18) */
 } mdk_gru_split;
 
 /*
@@ -196,6 +198,13 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   difference sat at the rounding-noise floor (a quarter of the threshold) the next call tries
  *                                                   the next smaller margin of the ladder; a trial that is rejected is repeated at the margin
  *                                                   that worked, and no shrink goes below a rejected margin again.  0: margins only grow.
+ *   "scan_split_probe"     = 1 | 0                  half precision, auto mode: a margin is used only after a call certified at it in
+ *                                                   FP32-PARITY mode (the same call run once more with hi/lo operands and the 2^-18
+ *                                                   threshold, result discarded: one extra forward per margin the learner visits
+ *                                                   and one per standing audit).  Half mode's own certificate compares fp16 images
+ *                                                   of h (threshold 2^-10) and cannot see an un-merged state below ~1e-3; without
+ *                                                   the probe its learner shrinks to margins fp32 parity rejects for the same
+ *                                                   weights.  0: trust the half certificate alone (environment MDK_SCAN_SPLIT_PROBE)
  *   "scan_split_audit"     = 1 | 0 | 2              1: the first certified call of a model -- and the first at every margin
  *                                                   it escalates to, and every "scan_split_audit_every"-th after that -- is
  *                                                   also run as the sequential scan and the two

@@ -154,6 +154,13 @@ struct mdk_gru {
     MarginLearner margin;                    // the margin in use, LEARNED per model: one rung up the ladder 64 .. 512 on a rejected
                                              // certificate, one rung down after `opt_split_adapt` certified calls at the noise floor
     int opt_split_adapt = 8;                 // certified calls at the noise floor before a smaller margin is tried (0: never shrink)
+    // half precision: a margin is used only after a call CERTIFIED AT IT IN FP32-PARITY MODE (a "probe": the same call, run once
+    // more with the hi/lo operands, threshold 2^-18, result discarded) -- half mode's own certificate compares fp16 images of h
+    // (threshold 2^-10) and cannot see an un-merged state below ~1e-3; see run_forward
+    int opt_split_probe = 1;                 // 0: half mode trusts its own certificate (round 5's behaviour)
+    std::vector<int> probed_ok;              // margins a probe certified
+    long probes_done = 0;
+    float probe_last_delta = 0.f;
     bool split_disabled = false;             // a certificate failed at the largest margin (or an audit failed): sequential scans (auto mode)
     long split_retry_in = 0;                 // ... for this many calls; then one more try at the largest margin (0: for good -- failed audits)
     long split_backoff = 0;                  // the last back-off (doubles per rejection at the largest margin: 64 .. 4096 calls)
@@ -271,6 +278,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     // process-wide defaults of the split scan (the options of the same names override them per model)
     if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
     if (const char *e = getenv("MDK_SCAN_SPLIT_ADAPT")) m->opt_split_adapt = std::max(atoi(e), 0);
+    if (const char *e = getenv("MDK_SCAN_SPLIT_PROBE")) m->opt_split_probe = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
         const int g = atoi(e);
         if (g >= 16 && g <= 4096 && g % 8 == 0) m->opt_split_margin = g;
@@ -476,6 +484,7 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         m->split_disabled = false;           // setting the option re-arms a model that fell back
         m->split_retry_in = m->split_backoff = 0;
         m->margin.reset(true);
+        m->probed_ok.clear();
     } else if (!strcmp(key, "scan_split_audit")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "scan_split_audit must be 0, 1 or 2");
         m->opt_split_audit = value;
@@ -486,6 +495,8 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
         if (value < 0) return fail(MDK_ERR_ARG, "scan_split_adapt must be >= 0 (certified calls at the noise floor before a smaller margin is tried; 0 = never)");
         m->opt_split_adapt = value;
         m->margin.quiet = 0;
+    } else if (!strcmp(key, "scan_split_probe")) {
+        m->opt_split_probe = value ? 1 : 0;
     } else if (!strcmp(key, "scan_split_margin")) {
         if (value < 16 || value > 4096 || value % 8) return fail(MDK_ERR_ARG, "scan_split_margin must be a multiple of 8 in 16..4096");
         m->opt_split_margin = value;
@@ -1512,6 +1523,8 @@ static void report_audits(mdk_gru *m) {
     m->last_split.audits = (int)std::min<long>(m->audits_done, 0x7fffffff);
     m->last_split.audit_failures = m->audit_failures;
     m->last_split.audit_worst_dp = m->audit_worst;
+    m->last_split.probes = (int)std::min<long>(m->probes_done, 0x7fffffff);
+    m->last_split.probe_max_delta = m->probe_last_delta;
 }
 
 // one call: split scan when the shape is latency-bound and the certificate holds, the sequential passes otherwise
@@ -1535,8 +1548,34 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
 #endif
     while (plan_split(m, B, T, sp)) {
         bool ok = false;
-        rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
-        if (rc) return rc;
+        // Half precision (what `medaka inference` runs by default, prediction.py:164-168).  Its certificate compares the fp16
+        // images the scan keeps of h: two merged scans still differ by 1e-4 .. 3e-4 of rounding noise there, the threshold is
+        // 2^-10, and a state that has NOT merged by up to 1e-3 passes unseen -- the margin learner then walks down to margins the
+        // fp32-parity certificate rejects for the same weights (round 5: 64 where fp32 parity needs 128).  So in auto mode a margin
+        // is used in half mode only after a call certified at it in FP32-PARITY mode: the call is run once more with the hi/lo
+        // operands and the 2^-18 threshold (result discarded, x stays on the device), once per margin the learner visits and again
+        // with every standing audit; a rejected probe is a rejected certificate (the margin climbs / the trial goes back).
+        const bool probe_due = m->precision == MDK_PREC_FP16 && m->opt_scan_split == 1 && m->opt_split_probe &&
+                               (std::find(m->probed_ok.begin(), m->probed_ok.end(), sp.G) == m->probed_ok.end() ||
+                                (m->opt_split_audit == 1 && m->opt_split_audit_every > 0 && m->split_calls_since_audit + 1 >= m->opt_split_audit_every));
+        bool probe_rejected = false;
+        if (probe_due) {
+            m->precision = MDK_PREC_FP32;
+            bool pok = false;
+            rc = run_split(m, sp, x_dev, probs_dev, s, x_host, nullptr, &pok);
+            m->precision = MDK_PREC_FP16;
+            if (rc) return rc;
+            x_host = nullptr;                     // x is on the device from here on
+            m->probes_done++;
+            m->probe_last_delta = m->last_split.max_delta;
+            m->probed_ok.erase(std::remove(m->probed_ok.begin(), m->probed_ok.end(), sp.G), m->probed_ok.end());
+            if (pok) m->probed_ok.push_back(sp.G);
+            else probe_rejected = true;
+        }
+        if (!probe_rejected) {
+            rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
+            if (rc) return rc;
+        }
         report_audits(m);
         if (keep) return MDK_OK;
         if (ok) {

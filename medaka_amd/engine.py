@@ -166,7 +166,8 @@ class GruEngine:
         _lib.check(_lib.load().mdk_gru_get_split(self._h, ctypes.byref(t)), "mdk_gru_get_split")
         return {"chunks": t.chunks, "margin": t.margin, "columns": t.columns, "status": _lib.SPLIT_STATUS.get(t.status, t.status),
                 "max_delta": t.max_delta, "fallbacks": t.fallbacks, "audited": bool(t.audited), "audit_max_dp": t.audit_max_dp,
-                "audits": t.audits, "audit_failures": t.audit_failures, "audit_worst_dp": t.audit_worst_dp}
+                "audits": t.audits, "audit_failures": t.audit_failures, "audit_worst_dp": t.audit_worst_dp,
+                "probes": t.probes, "probe_max_delta": t.probe_max_delta}
 
     # -- compute
     def forward_host(self, x, out=None):

@@ -44,7 +44,8 @@ class GruSplit(ctypes.Structure):
     _fields_ = [("chunks", ctypes.c_int), ("margin", ctypes.c_int), ("columns", ctypes.c_int),
                 ("status", ctypes.c_int), ("max_delta", ctypes.c_float), ("fallbacks", ctypes.c_int),
                 ("audited", ctypes.c_int), ("audit_max_dp", ctypes.c_float), ("audits", ctypes.c_int),
-                ("audit_failures", ctypes.c_int), ("audit_worst_dp", ctypes.c_float)]
+                ("audit_failures", ctypes.c_int), ("audit_worst_dp", ctypes.c_float), ("probes", ctypes.c_int),
+                ("probe_max_delta", ctypes.c_float)]
 
 
 class SplitShape(ctypes.Structure):
