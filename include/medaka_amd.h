@@ -68,7 +68,8 @@ typedef struct {
     int n_layers;
     int host_streamed;    /* split calls through mdk_gru_forward: bit 1 = the probabilities left in column chunks under the
                              second half of the last layer's scan (option "stream_host"; else one copy after the forward); bit 2 = x had
-                             been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call) */
+                             been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call); bit 3 = the
+                             forward itself had been enqueued ahead of the call (mdk_gru_forward_pipelined) */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
                              "fuse_proj"; its gi_ms is then 0 and its rec_ms covers both); bit 8: the classifier's Linear
                              ran inside the last layer's kernel as well ("fuse_head": head_ms is the combine kernel); bit 9: ... and the
@@ -136,6 +137,18 @@ int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_
  * return MDK_ERR_ARG -- call mdk_gru_forward instead.  Callable from another thread than the forwards. */
 int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T, unsigned long long *token);
 int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host);
+/* mdk_gru_forward_staged that also STARTS THE NEXT BATCH'S FORWARD before it waits for this one's last result chunk (no reference
+ * counterpart; `run_prediction` keeps one call in flight, prediction.py:44-52 -- this keeps the GPU busy between two of them).
+ * `next_probs_host` (B x T x num_classes fp32, page-locked): the buffer the caller will pass as `probs_host` of its NEXT call.  If
+ * the batch staged right after `token` (same B, T) is there, its forward is enqueued into the model's second context -- behind
+ * this call's last kernel where the two cannot share the chip, beside it where they can (sequential scans of <= 128
+ * work-groups) -- and its probabilities stream into `next_probs_host`; the call that redeems that token with that buffer finds
+ * its work in flight or done (mdk_gru_timing.host_streamed bit 3).  Same bits as a lone call.  The buffer must stay valid and
+ * untouched until that call has returned, or until mdk_gru_drop_pending / mdk_gru_destroy / any other entry of the model (all of
+ * which wait for the batch started ahead and forget it; its token is then spent: mdk_gru_forward answers).  NULL: exactly
+ * mdk_gru_forward_staged.  Option "early_start" = 0 (environment MDK_EARLY_START) turns the early start off. */
+int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host, float *next_probs_host);
+int mdk_gru_drop_pending(mdk_gru *m);
 
 /*
  * Same contraction with device-resident buffers (what `GRUModel.forward`, gru.py:58-72, is to

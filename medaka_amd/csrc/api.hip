@@ -33,6 +33,16 @@ using namespace mdk;
 
 #include "host_common.hpp"
 
+// HIP hands its streams out over a pool of hardware queues (GPU_MAX_HW_QUEUES per priority level, 4 by default), and streams
+// that share a queue are serialised -- a wait for an event in one of them holds up whatever the other put behind it.  A model
+// owns eleven streams (two contexts of five + the staging stream): on four queues the two contexts' side and copy streams
+// alias and two sequential scans that should run side by side run one after the other (149 -> 154 M columns/s; 221 M with 8
+// queues, profiles/r6_experiments/README.md).  The runtime reads the variable when it initialises, i.e. at the process's first
+// HIP call: a default is put into the environment when this library is loaded (an explicit setting wins; a process that has
+// used HIP before loading the library keeps what it started with -- `early_start` then still overlaps a forward with the
+// previous call's result copies, but not two sequential scans with each other).
+__attribute__((constructor)) static void mdk_default_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" const char *mdk_last_error(void) { return g_mdk_err.c_str(); }
 extern "C" const char *mdk_version(void) { return "medaka_amd 0.1 (gfx950)"; }
 
@@ -102,7 +112,44 @@ struct LayerDev {
     float *inv_scale_gi = nullptr;   // [D]
 };
 
-struct mdk_gru {
+// Everything ONE call in flight owns: workspace, flags, streams, event pools.  A model has two of these (mdk_gru below): the
+// staged entry (mdk_gru_forward_pipelined) enqueues the NEXT batch's forward into the one that is idle while the caller still
+// waits for the current batch's last result chunks -- every function of this file reaches these fields through `m->`, and
+// switching contexts is a swap of this base object (swap_ctx), not a change of the code that uses them.
+struct Ctx {
+    float *lpart = nullptr;     // partial logits of the fused head [D][n_tiles][T][8][5]
+    half8 *xfrag = nullptr;     // packed layer-0 input fragments
+    size_t xfrag_cap = 0;
+    int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
+    int *oor_host = nullptr;    // page-locked copy (host-checked fallback: calls that did not allocate gi)
+    size_t gi_rows = 0;         // rows gi is allocated for (0: not yet -- the throughput regime never touches it)
+    // workspace (grown on demand)
+    float *gi = nullptr;
+    float *act[2] = {nullptr, nullptr};
+    size_t ws_rows = 0;
+    float *p_dev = nullptr;     // the probabilities on the device (host entries)
+    size_t p_cap = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;              // projection GEMM of layer 1 under the tail of layer 0
+    hipStream_t copy_in = nullptr;           // host path: time slabs of x, host -> device, ahead of the layer-0 recurrence
+    hipStream_t copy_out = nullptr;          // host path: finished probability columns, device -> host
+    hipStream_t copy_out2 = nullptr;         // split host path: every other chunk copy (two DMA engines side by side)
+    std::vector<hipEvent_t> ov_ev;           // event pool of one forward pass (no timing)
+    size_t ov_next = 0;
+    float *gi2 = nullptr;                    // its own gi buffer (layer 0's fallback may still read gi)
+    size_t gi2_rows = 0;
+    float *xv = nullptr;                     // the virtual batch
+    size_t xv_cap = 0;
+    unsigned *split_flag = nullptr;          // device: bits of the largest junction difference per certificate point
+    unsigned *split_host = nullptr;          // page-locked copy of split_flag
+    mdk_gru_timing last{};
+    std::vector<hipEvent_t> ev;
+    hipEvent_t kernels_done = nullptr;       // behind the last KERNEL of the pass(es) this context enqueued last (its result copies may still run)
+    int last_wgs = 0;                        // recurrence work-groups (x directions x gpu_share) of that pass: 0 = nothing enqueued yet
+};
+
+struct mdk_gru : Ctx {
+    Ctx other;                  // the second context (streams and buffers created on first use: init_ctx)
     mdk_gru_desc desc{};
     int device = 0;
     int D = 2;
@@ -116,34 +163,15 @@ struct mdk_gru {
     int opt_fuse_head = 1;      // last layer with a fused projection: Linear(D*128 -> 5) inside the recurrence kernel too (rec_fused.hpp HEAD)
     half8 *wlin_frag = nullptr; // [D][4 ksteps][2 hi/lo][64 lanes] B-fragments of linear.weight (classes padded to 16 columns)
     float lin_inv_scale = 1.f;  // 1 / (kActScale * their operand scale)
-    float *lpart = nullptr;     // partial logits of the fused head [D][n_tiles][T][8][5]
     int opt_fuse_proj = 1;      // layers >= 1: projection fused into the recurrence (rec_fused.hpp): 0 off, 1 when the call fills the chip, 2 always
-    half8 *xfrag = nullptr;     // packed layer-0 input fragments
-    size_t xfrag_cap = 0;
-    int *oor_flag = nullptr;    // device flag: layer-0 input out of fp16 range -> unfused path
-    int *oor_host = nullptr;    // page-locked copy (host-checked fallback: calls that did not allocate gi)
     bool oor_seen = false;      // an input left the fp16 range once: gi stays allocated and the fallback decides on the device again
-    size_t gi_rows = 0;         // rows gi is allocated for (0: not yet -- the throughput regime never touches it)
     std::vector<LayerDev> layers;
     float *lin_w = nullptr, *lin_b = nullptr;
-    // workspace (grown on demand)
-    float *gi = nullptr;
-    float *act[2] = {nullptr, nullptr};
-    size_t ws_rows = 0;
     // host-API staging
-    float *x_dev = nullptr, *p_dev = nullptr;
-    size_t x_cap = 0, p_cap = 0;
+    float *x_dev = nullptr;     // x of a host call (the staged entry reads its staging slot instead)
+    size_t x_cap = 0;
     unsigned char *aux_dev = nullptr;   // raw counts + depth in, decoded classes + probabilities out
     size_t aux_cap = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;              // projection GEMM of layer 1 under the tail of layer 0
-    hipStream_t copy_in = nullptr;           // host path: time slabs of x, host -> device, ahead of the layer-0 recurrence
-    hipStream_t copy_out = nullptr;          // host path: finished probability columns, device -> host
-    hipStream_t copy_out2 = nullptr;         // split host path: every other chunk copy (two DMA engines side by side)
-    std::vector<hipEvent_t> ov_ev;           // event pool of one forward pass (no timing)
-    size_t ov_next = 0;
-    float *gi2 = nullptr;                    // its own gi buffer (layer 0's fallback may still read gi)
-    size_t gi2_rows = 0;
     int opt_overlap = 1;
     int opt_deferred_store = 1;              // recurrence: HBM store of h_t from inside step t+1 (rec_mfma.hpp DS)
     int opt_gpu_share = 1;                   // processes sharing this GPU (launch.py --procs-per-gpu): divides the CU budgets below
@@ -164,10 +192,6 @@ struct mdk_gru {
     bool split_disabled = false;             // a certificate failed at the largest margin (or an audit failed): sequential scans (auto mode)
     long split_retry_in = 0;                 // ... for this many calls; then one more try at the largest margin (0: for good -- failed audits)
     long split_backoff = 0;                  // the last back-off (doubles per rejection at the largest margin: 64 .. 4096 calls)
-    float *xv = nullptr;                     // the virtual batch
-    size_t xv_cap = 0;
-    unsigned *split_flag = nullptr;          // device: bits of the largest junction difference per certificate point
-    unsigned *split_host = nullptr;          // page-locked copy of split_flag
     mdk_gru_split last_split{};
     int opt_split_audit = 1;                 // 0 never, 1 the first certified call of every margin, 2 every certified call
     int split_audited_key = 0;               // margin | precision << 16 whose first certified call has been audited (0 = none yet)
@@ -192,33 +216,76 @@ struct mdk_gru {
     float audit_worst = 0.f;
     // timing
     bool timing = false;
-    mdk_gru_timing last{};
-    std::vector<hipEvent_t> ev;
+    // the NEXT batch's forward, enqueued ahead of its call (mdk_gru_forward_pipelined): lives in `other` while valid
+    struct Started {
+        bool valid = false;
+        bool split = false;                  // enqueued as a split scan (its certificate is still unread) / as sequential passes
+        SplitPlan sp{};
+        bool need_gi = false;
+        int precision = 0;
+        std::vector<hipEvent_t> out_done;    // (unused after the enqueue: the stream waits for them itself)
+    };
+    struct Pending { Started st; unsigned long long token = 0; StageSlot *slot = nullptr; int B = 0, T = 0; float *probs_host = nullptr; } pending;
+    int opt_early_start = 1;                 // 0: the staged entry never starts the next batch's forward ahead of its call
+    long early_started = 0, early_used = 0, early_dropped = 0;
 };
 
+
+// ---- the two contexts of a model
+static void swap_ctx(mdk_gru *m) { std::swap(static_cast<Ctx &>(*m), m->other); }
+
+// streams and flags of the CURRENT context (create: the first; the second on its first use -- swap, init, swap back)
+static int init_ctx(mdk_gru *m) {
+    if (m->stream) return MDK_OK;
+    // The stream the recurrences run on gets a priority of its own: HIP hands its streams out over a small pool of hardware
+    // queues PER PRIORITY (GPU_MAX_HW_QUEUES = 4 by default), and two streams that land on one queue are serialised -- with five
+    // streams per context and two contexts the main streams of both shared a queue, and two sequential scans that should have
+    // run side by side ran one after the other (profiles/r6_experiments/README.md: 149 -> 154 M columns/s with the default pool,
+    // 221 M with 8 queues).  The two main streams are the only high-priority streams of the model: a queue each.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->copy_out2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->kernels_done, hipEventDisableTiming) != hipSuccess)
+        return fail(MDK_ERR_DEVICE, "hipStreamCreate failed");
+    if (hipMalloc((void **)&m->oor_flag, 8192) != hipSuccess) return fail(MDK_ERR_OOM, "hipMalloc failed");
+    (void)hipMemset(m->oor_flag, 0, 8192);
+    return MDK_OK;
+}
+
+static void free_ctx(Ctx &c) {
+    free_dev(c.lpart); free_dev(c.gi); free_dev(c.act[0]); free_dev(c.act[1]); free_dev(c.gi2); free_dev(c.p_dev);
+    free_dev(c.xfrag); free_dev(c.oor_flag); free_dev(c.xv); free_dev(c.split_flag);
+    if (c.split_host) (void)hipHostFree(c.split_host);
+    if (c.oor_host) (void)hipHostFree(c.oor_host);
+    for (auto e : c.ev) (void)hipEventDestroy(e);
+    for (auto e : c.ov_ev) (void)hipEventDestroy(e);
+    if (c.kernels_done) (void)hipEventDestroy(c.kernels_done);
+    for (hipStream_t st : {c.stream, c.side, c.copy_in, c.copy_out, c.copy_out2})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    c = Ctx{};
+}
+
+static void drop_pending(mdk_gru *m);
 
 extern "C" void mdk_gru_destroy(mdk_gru *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    drop_pending(m);
     for (auto &L : m->layers) {
         free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
         free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.wx_frag); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
     }
-    free_dev(m->wlin_frag); free_dev(m->lpart);
-    free_dev(m->lin_w); free_dev(m->lin_b); free_dev(m->gi); free_dev(m->act[0]); free_dev(m->act[1]);
-    free_dev(m->gi2); free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->p_dev); free_dev(m->xfrag); free_dev(m->oor_flag);
-    free_dev(m->xv); free_dev(m->split_flag); free_dev(m->audit);
+    free_dev(m->wlin_frag);
+    free_dev(m->lin_w); free_dev(m->lin_b);
+    free_ctx(static_cast<Ctx &>(*m));
+    free_ctx(m->other);
+    free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->audit);
     if (m->stage_stream) { (void)hipStreamSynchronize(m->stage_stream); (void)hipStreamDestroy(m->stage_stream); }
     for (auto &sl : m->stage) { free_dev(sl.dev); if (sl.ready) (void)hipEventDestroy(sl.ready); }
-    if (m->split_host) (void)hipHostFree(m->split_host);
-    if (m->oor_host) (void)hipHostFree(m->oor_host);
-    for (auto e : m->ev) (void)hipEventDestroy(e);
-    for (auto e : m->ov_ev) (void)hipEventDestroy(e);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
-    if (m->side) (void)hipStreamDestroy(m->side);
-    if (m->copy_in) (void)hipStreamDestroy(m->copy_in);
-    if (m->copy_out) (void)hipStreamDestroy(m->copy_out);
-    if (m->copy_out2) (void)hipStreamDestroy(m->copy_out2);
     delete m;
 }
 
@@ -279,18 +346,14 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     if (const char *e = getenv("MDK_SCAN_SPLIT")) m->opt_scan_split = std::min(std::max(atoi(e), 0), kMaxSplit);
     if (const char *e = getenv("MDK_SCAN_SPLIT_ADAPT")) m->opt_split_adapt = std::max(atoi(e), 0);
     if (const char *e = getenv("MDK_SCAN_SPLIT_PROBE")) m->opt_split_probe = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MDK_EARLY_START")) m->opt_early_start = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
         const int g = atoi(e);
         if (g >= 16 && g <= 4096 && g % 8 == 0) m->opt_split_margin = g;
     }
     int rc = MDK_OK;
     auto bail = [&](int code) { mdk_gru_destroy(m); return code; };
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_out2, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(MDK_ERR_DEVICE, "hipStreamCreate failed"));
+    if ((rc = init_ctx(m))) return bail(rc);
 
     for (int l = 0; l < L; ++l) {
         LayerDev &Ld = m->layers[l];
@@ -411,8 +474,6 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
             }
         }
     }
-    if (hipMalloc((void **)&m->oor_flag, 8192) != hipSuccess) return bail(fail(MDK_ERR_OOM, "hipMalloc failed"));
-    (void)hipMemset(m->oor_flag, 0, 8192);
     if ((rc = upload_classifier(m, weights[4 * L * D], weights[4 * L * D + 1]))) return bail(rc);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gi_gemm<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGemmMT * 8 * 64 * 16));
@@ -433,23 +494,30 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
 extern "C" int mdk_gru_set_precision(mdk_gru *m, int precision) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (precision != MDK_PREC_FP32 && precision != MDK_PREC_FP16) return fail(MDK_ERR_ARG, "bad precision %d", precision);
+    if (precision != m->precision) { (void)hipSetDevice(m->device); drop_pending(m); }
     m->precision = precision;
     return MDK_OK;
 }
 extern "C" int mdk_gru_set_variant(mdk_gru *m, int variant) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (variant != MDK_VARIANT_MFMA && variant != MDK_VARIANT_EXACT) return fail(MDK_ERR_ARG, "bad variant %d", variant);
+    if (variant != m->variant) { (void)hipSetDevice(m->device); drop_pending(m); }
     m->variant = variant;
     return MDK_OK;
 }
 extern "C" int mdk_gru_set_normalise(mdk_gru *m, int normalise) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
+    if ((normalise ? 1 : 0) != m->desc.normalise) { (void)hipSetDevice(m->device); drop_pending(m); }
     m->desc.normalise = normalise ? 1 : 0;
     return MDK_OK;
 }
 extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     if (!m || !key) return fail(MDK_ERR_ARG, "null argument");
-    if (!strcmp(key, "rec_windows_per_tile")) {
+    (void)hipSetDevice(m->device);
+    drop_pending(m);                 // (a batch started ahead was planned under the old options)
+    if (!strcmp(key, "early_start")) {
+        m->opt_early_start = value ? 1 : 0;
+    } else if (!strcmp(key, "rec_windows_per_tile")) {
         if (value != 0 && value != 4 && value != 8 && value != 16)
             return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
         m->opt_tile_windows = value;
@@ -1254,6 +1322,10 @@ int Pass::run() {
     if (!head_done) launch_head(in, s, 0, T);
     if ((rc = tm.end())) return rc;
     HIP_TRY(hipGetLastError());
+    // every kernel of the pass is enqueued (a split call adds its certificate kernel and records again): what the OTHER context's
+    // next forward waits for where two passes cannot share the chip -- not for the result copies that follow
+    HIP_TRY(hipEventRecord(m->kernels_done, s));
+    m->last_wgs = P.n_wg * P.D * m->opt_gpu_share;
     return copy_out();
 }
 
@@ -1443,8 +1515,11 @@ static bool plan_split(const mdk_gru *m, int B, int T, SplitPlan &p) {
                             m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass, p);
 }
 
-static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
-                     const float *x_host, float *probs_host, bool *certified) {
+// A split call in two halves, so that the staged entry can enqueue the NEXT batch's forward before it waits for this one's
+// certificate: split_enqueue = every launch and copy of the call (nothing here waits for the device), split_finish = the wait,
+// the range flag, the certificate.  run_split = one after the other.
+static int split_enqueue(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
+                         const float *x_host, float *probs_host, EvTimer &tm, bool *need_gi) {
     const size_t F = m->desc.num_features;
     const int Bv = sp.S * sp.B;
     const size_t cols = (size_t)Bv * sp.Tv;
@@ -1457,11 +1532,13 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     }
     if (!m->split_flag) HIP_TRY(hipMalloc((void **)&m->split_flag, kSplitFlagWords * sizeof(unsigned)));
     if (!m->split_host) HIP_TRY(hipHostMalloc((void **)&m->split_host, kSplitFlagWords * sizeof(unsigned), hipHostMallocDefault));
+    if (!m->oor_host) HIP_TRY(hipHostMalloc((void **)&m->oor_host, sizeof(int), hipHostMallocDefault));
     HostIO io;
     io.p_host = probs_host;
     PassPlan P;                    // this call synchronises for its certificate anyway: it looks at the range flag itself
     int rc = plan_pass(m, Bv, sp.Tv, probs_host ? &io : nullptr, &sp, P, /*host_checks_range=*/true);
     if (rc) return rc;
+    *need_gi = P.need_gi;
     if ((rc = ensure_workspace(m, (((size_t)Bv + kTileWin - 1) / kTileWin * kTileWin) * (size_t)sp.Tv, P.need_gi))) return rc;
     HIP_TRY(hipMemsetAsync(m->split_flag, 0, kSplitFlagWords * sizeof(unsigned), s));
     // Host buffers.  x crosses PCIe whole, one contiguous copy in front of the forward: all of it is needed within the
@@ -1475,7 +1552,6 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     // What stays exposed is the last launch's chunk; a shape that cannot be chunked leaves as one copy behind the forward.
     if (x_host)
         HIP_TRY(hipMemcpyAsync(const_cast<float *>(x_dev), x_host, (size_t)sp.B * sp.T * F * sizeof(float), hipMemcpyHostToDevice, s));
-    EvTimer tm{m, s};
     std::vector<hipEvent_t> out_done;      // (the last result chunks are still crossing PCIe while the certificate is computed)
     // (x_dev is the REAL batch: layer 0's operands are packed straight from it, chunk by chunk; m->xv -- the virtual batch in
     // memory -- is written only if the exact-projection fallback needs it)
@@ -1484,16 +1560,32 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     hipLaunchKernelGGL(k_split_verify, dim3((unsigned)((sp.B + kVerifyWin - 1) / kVerifyWin), (unsigned)(8 * (sp.S - 1))), dim3(128), 0, s,
                        (const float *)m->act[0], (const float *)m->act[1], sp, m->split_flag);
     HIP_TRY(hipMemcpyAsync(m->split_host, m->split_flag, kSplitFlagWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    // (no gi, hence no device-side fallback in this pass: the range flag goes home with the certificate)
+    if (!P.need_gi) HIP_TRY(hipMemcpyAsync(m->oor_host, m->oor_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(m->kernels_done, s));        // the call's last kernel: the other context's next forward may start behind it
     for (hipEvent_t e : out_done) HIP_TRY(hipStreamWaitEvent(s, e, 0));
     HIP_TRY(hipGetLastError());
+    return MDK_OK;
+}
+
+static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
+                     const float *x_host, float *probs_host, bool *certified);
+
+static int split_finish(mdk_gru *m, const SplitPlan &sp, bool need_gi, EvTimer &tm, const float *x_dev, float *probs_dev, hipStream_t s,
+                        float *probs_host, bool *certified) {
+    int rc;
     if ((rc = finish_timing(m, tm, s))) return rc;
-    if (!P.need_gi) {
-        // no gi, hence no device-side fallback in this pass: was the input inside fp16 range?  (x is on the device by now)
-        bool raised = false;
-        if ((rc = range_flag_raised(m, s, &raised))) return rc;
-        if (raised) return run_split(m, sp, x_dev, probs_dev, s, nullptr, probs_host, certified);
-    }
     HIP_TRY(hipStreamSynchronize(s));      // the certificate decides what this call returns
+    if (!need_gi && *m->oor_host != 0) {
+        // the input left the fp16 range and nothing was there to take over: the model is marked and the call repeated, with gi
+        // and the device-side decision, which later calls keep
+        if (!m->oor_seen) {
+            m->oor_seen = true;
+            fprintf(stderr, "[medaka_amd] input beyond fp16 range (un-normalised counts?): the exact fp32 projection takes over -- this call is "
+                            "repeated, later ones decide on the device\n");
+        }
+        return run_split(m, sp, x_dev, probs_dev, s, nullptr, probs_host, certified);
+    }
     const float eps = m->precision == MDK_PREC_FP16 ? kSplitEpsHalf : kSplitEps;
     float worst = 0.f;
     for (int y = 0; y < 8 * (sp.S - 1); ++y) {
@@ -1519,6 +1611,15 @@ static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float 
     return MDK_OK;
 }
 
+static int run_split(mdk_gru *m, const SplitPlan &sp, const float *x_dev, float *probs_dev, hipStream_t s,
+                     const float *x_host, float *probs_host, bool *certified) {
+    EvTimer tm{m, s};
+    bool need_gi = true;
+    int rc = split_enqueue(m, sp, x_dev, probs_dev, s, x_host, probs_host, tm, &need_gi);
+    if (rc) return rc;
+    return split_finish(m, sp, need_gi, tm, x_dev, probs_dev, s, probs_host, certified);
+}
+
 static void report_audits(mdk_gru *m) {
     m->last_split.audits = (int)std::min<long>(m->audits_done, 0x7fffffff);
     m->last_split.audit_failures = m->audit_failures;
@@ -1528,10 +1629,34 @@ static void report_audits(mdk_gru *m) {
 }
 
 // one call: split scan when the shape is latency-bound and the certificate holds, the sequential passes otherwise
+// `pre` (staged entry only): the call's FIRST attempt is already enqueued on `s` in this context (start_call) -- a split scan whose
+// certificate is still unread, or the sequential passes.  It is taken over if it is what this function would have enqueued now;
+// otherwise (an option, the learner or the back-off moved in between) it is waited for and forgotten.
+static bool same_split(const SplitPlan &a, const SplitPlan &b) {
+    if (a.S != b.S || a.B != b.B || a.T != b.T || a.Tv != b.Tv || a.G != b.G) return false;
+    for (int k = 0; k < a.S; ++k) if (a.start[k] != b.start[k] || a.core0[k] != b.core0[k]) return false;
+    return a.core0[a.S] == b.core0[b.S];
+}
+
+static bool split_probe_due(const mdk_gru *m, const SplitPlan &sp) {
+    return m->precision == MDK_PREC_FP16 && m->opt_scan_split == 1 && m->opt_split_probe &&
+           (std::find(m->probed_ok.begin(), m->probed_ok.end(), sp.G) == m->probed_ok.end() ||
+            (m->opt_split_audit == 1 && m->opt_split_audit_every > 0 && m->split_calls_since_audit + 1 >= m->opt_split_audit_every));
+}
+
 static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s,
-                       const float *x_host, float *probs_host) {
+                       const float *x_host, float *probs_host, mdk_gru::Started *pre = nullptr) {
     SplitPlan sp;
     int rc;
+    bool first_attempt = true;
+    auto forget_pre = [&]() -> int {
+        if (pre && pre->valid) {
+            pre->valid = false;
+            m->early_dropped++;
+            HIP_TRY(hipStreamSynchronize(s));       // (its result copies target the caller's buffer: nothing of it may still be running)
+        }
+        return MDK_OK;
+    };
     const int fallbacks = m->last_split.fallbacks;
     memset(&m->last_split, 0, sizeof(m->last_split));
     m->last_split.chunks = 1; m->last_split.columns = T; m->last_split.fallbacks = fallbacks;
@@ -1555,9 +1680,11 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         // is used in half mode only after a call certified at it in FP32-PARITY mode: the call is run once more with the hi/lo
         // operands and the 2^-18 threshold (result discarded, x stays on the device), once per margin the learner visits and again
         // with every standing audit; a rejected probe is a rejected certificate (the margin climbs / the trial goes back).
-        const bool probe_due = m->precision == MDK_PREC_FP16 && m->opt_scan_split == 1 && m->opt_split_probe &&
-                               (std::find(m->probed_ok.begin(), m->probed_ok.end(), sp.G) == m->probed_ok.end() ||
-                                (m->opt_split_audit == 1 && m->opt_split_audit_every > 0 && m->split_calls_since_audit + 1 >= m->opt_split_audit_every));
+        const bool probe_due = split_probe_due(m, sp);
+        const bool use_pre = first_attempt && pre && pre->valid && pre->split && pre->precision == m->precision && !probe_due &&
+                             same_split(sp, pre->sp);
+        if (first_attempt && !use_pre && (rc = forget_pre())) return rc;
+        first_attempt = false;
         bool probe_rejected = false;
         if (probe_due) {
             m->precision = MDK_PREC_FP32;
@@ -1573,7 +1700,14 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
             else probe_rejected = true;
         }
         if (!probe_rejected) {
-            rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
+            if (use_pre) {
+                pre->valid = false;
+                m->early_used++;
+                EvTimer none{m, s};
+                rc = split_finish(m, sp, pre->need_gi, none, x_dev, probs_dev, s, probs_host, &ok);
+            } else {
+                rc = run_split(m, sp, x_dev, probs_dev, s, x_host, probs_host, &ok);
+            }
             if (rc) return rc;
         }
         report_audits(m);
@@ -1681,9 +1815,58 @@ static int run_forward(mdk_gru *m, const float *x_dev, int B, int T, float *prob
         fprintf(stderr, "[medaka_amd] split scan: junction states differed by %.3g at a margin of %d columns: margin %d from now on\n",
                 m->last_split.max_delta, sp.G, next);
     }
+    if (first_attempt && pre && pre->valid && !pre->split && pre->precision == m->precision) {
+        pre->valid = false;            // the sequential passes are what start_call enqueued: the caller's synchronize ends them
+        m->early_used++;
+        report_audits(m);
+        return MDK_OK;
+    }
+    if ((rc = forget_pre())) return rc;
     rc = run_passes(m, x_dev, B, T, probs_dev, s, x_host, probs_host);
     report_audits(m);
     return rc;
+}
+
+// The first attempt of a call, enqueue only: what run_forward would launch for (x_dev, B, T) right now -- a split scan at the
+// margin in use, or the sequential passes -- WITHOUT waiting for anything.  Not started (st->valid stays false; run_forward then
+// does everything): timing on, a probe due, more than one pass, the exact kernels.  `prev`: the other context; where the two
+// forwards cannot share the chip this one's kernels are ordered behind that one's (its result copies are not waited for).
+static int start_call(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev, hipStream_t s, float *probs_host,
+                      mdk_gru::Started *st, const Ctx *prev) {
+    st->valid = false;
+    if (m->timing || m->variant != MDK_VARIANT_MFMA) return MDK_OK;
+    SplitPlan sp;
+    int rc;
+    // (the back-off of a model whose certificate was rejected at the largest margin counts calls in run_forward: a call that
+    // would end it is left to run_forward)
+    if (m->split_disabled && m->split_retry_in == 1) return MDK_OK;
+    const bool split = plan_split(m, B, T, sp);
+    if (split && split_probe_due(m, sp)) return MDK_OK;
+    const size_t budget = m->max_rows_per_pass ? m->max_rows_per_pass : kMaxRowsPerPass;
+    if (!split && (size_t)B * T > budget) return MDK_OK;
+    int wgs = 256;
+    if (!split) {
+        PassPlan P;
+        HostIO io;
+        io.p_host = probs_host;
+        if ((rc = plan_pass(m, B, T, &io, nullptr, P))) return rc;
+        wgs = P.n_wg * P.D * m->opt_gpu_share;
+    }
+    // two forwards side by side only where both leave the other its CUs (sequential scans of the reference's batch sizes: 100 of
+    // 256 CUs each); a recurrence that holds every CU tolerates nothing beside it (profiles/r4_experiments/README.md)
+    if (prev && prev->kernels_done && prev->last_wgs > 0 && (split || wgs + prev->last_wgs > 256))
+        HIP_TRY(hipStreamWaitEvent(s, prev->kernels_done, 0));
+    st->split = split;
+    st->precision = m->precision;
+    if (split) {
+        EvTimer none{m, s};
+        st->sp = sp;
+        if ((rc = split_enqueue(m, sp, x_dev, probs_dev, s, nullptr, probs_host, none, &st->need_gi))) return rc;
+    } else {
+        if ((rc = run_passes(m, x_dev, B, T, probs_dev, s, nullptr, probs_host))) return rc;
+    }
+    st->valid = true;
+    return MDK_OK;
 }
 
 extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T, float *probs_dev,
@@ -1693,6 +1876,7 @@ extern "C" int mdk_gru_forward_dev(mdk_gru *m, const float *x_dev, int B, int T,
     if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); m->last.n_layers = m->desc.num_layers; return MDK_OK; }
     if (!x_dev || !probs_dev) return fail(MDK_ERR_ARG, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
+    drop_pending(m);
     // NULL = the legacy default stream, as for any HIP call
     return run_forward(m, x_dev, B, T, probs_dev, (hipStream_t)stream, nullptr, nullptr);
 }
@@ -1758,12 +1942,98 @@ extern "C" int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T
     return MDK_OK;
 }
 
-extern "C" int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host) {
+// ---- the next batch's forward, started ahead of its call ---------------------------------------------------------------------
+// A staged call returns when its last result chunk has crossed PCIe and its certificate has been read: 0.5 - 1 ms during
+// which the GPU has nothing to do (the second half of the last scan produces 40 MB of probabilities about as fast as one
+// DMA engine ships them), then the caller's own work between two calls, then the launches of the next forward.  With the
+// reference's loader (prediction.py:225-370) the next batch is usually on the device already (mdk_gru_stage_input): its
+// forward is enqueued -- into the model's second context, results straight into the buffer the caller promises for it --
+// BEFORE this call waits, ordered behind this call's last kernel (two recurrences that each hold every CU cannot share the
+// chip; two sequential scans of the reference's batch sizes can, and then run side by side).  The call that redeems the next
+// token finds its work in flight or done and only reads the certificate.  Bits: those of a lone call (same plan, same
+// kernels, same margin -- a batch started ahead whose plan has moved by its call is waited for and recomputed).
+static void release_slot(mdk_gru *m, mdk_gru::StageSlot *sl) {
+    std::lock_guard<std::mutex> lock(m->stage_mu);
+    sl->busy = false;
+}
+
+// nothing of a batch started ahead may survive: wait for it, free its slot (its token is spent: the caller's ordinary host
+// entry answers).  Every entry but the pipelined one starts with this.
+static void drop_pending(mdk_gru *m) {
+    if (!m->pending.st.valid) return;
+    m->pending.st.valid = false;
+    m->early_dropped++;
+    swap_ctx(m);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    swap_ctx(m);
+    if (m->pending.slot) release_slot(m, m->pending.slot);
+    m->pending.slot = nullptr;
+}
+
+extern "C" int mdk_gru_drop_pending(mdk_gru *m) {
+    if (!m) return fail(MDK_ERR_ARG, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    drop_pending(m);
+    return MDK_OK;
+}
+
+// enqueue the forward of the batch staged right after `token` (same shape), if it is there, into the other context
+static int try_early_start(mdk_gru *m, unsigned long long token, int B, int T, float *next_probs_host) {
+    if (!m->opt_early_start || !next_probs_host || m->pending.st.valid || m->timing) return MDK_OK;
+    // a call that the learner will move (a smaller margin on trial) or that an audit / probe will repeat is not worth starting:
+    // its plan is not known before the current call has been judged
+    if (m->opt_scan_split == 1 && m->opt_split_adapt > 0 && m->margin.quiet + 2 >= m->opt_split_adapt) return MDK_OK;
+    if (m->margin.trial_back) return MDK_OK;
+    if (m->opt_scan_split && m->opt_split_audit == 1 &&
+        (m->split_audited_key == 0 || (m->opt_split_audit_every > 0 && m->split_calls_since_audit + 2 >= m->opt_split_audit_every))) return MDK_OK;
+    if (m->opt_split_audit == 2) return MDK_OK;
+    mdk_gru::StageSlot *sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(m->stage_mu);
+        for (auto &c : m->stage)
+            if (c.token == token + 1 && c.B == B && c.T == T && !c.busy) { sl = &c; c.busy = true; c.token = 0; }
+    }
+    if (!sl) return MDK_OK;
+    swap_ctx(m);                               // the idle context becomes the current one
+    int rc = init_ctx(m);
+    if (!rc) rc = ensure_staging(m, 0, (size_t)B * T * m->desc.num_classes);
+    if (!rc && hipStreamWaitEvent(m->stream, sl->ready, 0) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamWaitEvent failed");
+    mdk_gru::Started st;
+    if (!rc) rc = start_call(m, sl->dev, B, T, m->p_dev, m->stream, next_probs_host, &st, &m->other);
+    if (rc) (void)hipStreamSynchronize(m->stream);
+    swap_ctx(m);
+    if (rc || !st.valid) {
+        std::lock_guard<std::mutex> lock(m->stage_mu);      // not started: the token is good again
+        sl->token = token + 1;
+        sl->busy = false;
+        return rc;
+    }
+    m->pending.st = st;
+    m->pending.token = token + 1; m->pending.slot = sl; m->pending.B = B; m->pending.T = T; m->pending.probs_host = next_probs_host;
+    m->early_started++;
+    return MDK_OK;
+}
+
+extern "C" int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host, float *next_probs_host) {
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (!probs_host || token == 0) return fail(MDK_ERR_ARG, "null buffer / token");
     HIP_TRY(hipSetDevice(m->device));
     mdk_gru::StageSlot *sl = nullptr;
-    {
+    mdk_gru::Started pre;
+    bool from_pending = false;
+    if (m->pending.st.valid) {
+        if (m->pending.token == token && m->pending.B == B && m->pending.T == T && m->pending.probs_host == probs_host) {
+            swap_ctx(m);                       // the context this batch was started in becomes the current one
+            from_pending = true;
+            pre = m->pending.st;
+            sl = m->pending.slot;
+            m->pending.st.valid = false;
+            m->pending.slot = nullptr;
+        } else {
+            drop_pending(m);                   // another batch, or another buffer than the one promised: its token is spent
+        }
+    }
+    if (!sl) {
         std::lock_guard<std::mutex> lock(m->stage_mu);
         for (auto &c : m->stage)
             if (c.token == token && c.B == B && c.T == T && !c.busy) { sl = &c; c.busy = true; c.token = 0; m->stage_unredeemed = 0; }
@@ -1771,17 +2041,27 @@ extern "C" int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int 
     if (!sl) return fail(MDK_ERR_ARG, "unknown or expired staging token (use mdk_gru_forward)");
     const size_t np = (size_t)B * T * m->desc.num_classes;
     int rc = ensure_staging(m, 0, np);
-    if (!rc && hipStreamWaitEvent(m->stream, sl->ready, 0) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamWaitEvent failed");
-    if (!rc) rc = run_forward(m, sl->dev, B, T, m->p_dev, m->stream, nullptr, probs_host);
+    if (!rc && !pre.valid) {
+        if (hipStreamWaitEvent(m->stream, sl->ready, 0) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamWaitEvent failed");
+        // this call's own first attempt, enqueue only -- so that the next batch's can follow it before anything is waited for
+        if (!rc && next_probs_host) rc = start_call(m, sl->dev, B, T, m->p_dev, m->stream, probs_host, &pre, m->other.stream ? &m->other : nullptr);
+    }
+    if (!rc && pre.valid) rc = try_early_start(m, token, B, T, next_probs_host);
+    const long used_before = m->early_used;
+    if (!rc) rc = run_forward(m, sl->dev, B, T, m->p_dev, m->stream, nullptr, probs_host, &pre);
     if (rc) (void)hipDeviceSynchronize();
     else if (hipStreamSynchronize(m->stream) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamSynchronize failed");
-    {
-        std::lock_guard<std::mutex> lock(m->stage_mu);
-        sl->busy = false;
-    }
+    release_slot(m, sl);
     m->staged_used++;
     m->last.host_streamed |= 4;
+    if (from_pending && m->early_used != used_before) m->last.host_streamed |= 8;
+    // the batch behind this one may have landed only now: its forward then runs under whatever the caller does between two calls
+    if (!rc) rc = try_early_start(m, token, B, T, next_probs_host);
     return rc;
+}
+
+extern "C" int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host) {
+    return mdk_gru_forward_pipelined(m, token, B, T, probs_host, nullptr);
 }
 
 extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_host) {
@@ -1790,6 +2070,7 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
     if (B == 0 || T == 0) { memset(&m->last, 0, sizeof(m->last)); return MDK_OK; }
     if (!x_host || !probs_host) return fail(MDK_ERR_ARG, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
+    drop_pending(m);
     const size_t nx = (size_t)B * T * m->desc.num_features, np = (size_t)B * T * m->desc.num_classes;
     int rc = ensure_staging(m, nx, np);
     if (rc) return rc;
@@ -1837,6 +2118,7 @@ static int forward_any(mdk_gru *m, const float *x_host, const uint16_t *counts_h
     if (!probs_host && !(cls_host && pmax_host)) return fail(MDK_ERR_ARG, "no output requested (probs, or cls + pmax)");
     if ((cls_host == nullptr) != (pmax_host == nullptr)) return fail(MDK_ERR_ARG, "cls and pmax go together");
     HIP_TRY(hipSetDevice(m->device));
+    drop_pending(m);
     const int F = m->desc.num_features, C = m->desc.num_classes;
     const size_t cols = (size_t)B * T, nx = cols * F, np = cols * C;
     { int rc0 = ensure_staging(m, nx, np); if (rc0) return rc0; }

@@ -243,13 +243,40 @@ class GruEngine:
             _lib.check(_lib.load().mdk_gru_stage_input(self._h, x_ptr, int(B), int(T), ctypes.byref(tok)), "mdk_gru_stage_input")
         return tok.value
 
-    def forward_staged(self, token, B, T, out_ptr):
-        """The forward of a staged batch; False if the token is no longer valid (then use the ordinary host forward)."""
-        rc = _lib.load().mdk_gru_forward_staged(self._h, ctypes.c_ulonglong(token), int(B), int(T), out_ptr)
+    def forward_staged(self, token, B, T, out_ptr, next_out_ptr=None):
+        """The forward of a staged batch; False if the token is no longer valid (then use the ordinary host forward).
+        `next_out_ptr`: the page-locked buffer the NEXT call's result will be asked into (`mdk_gru_forward_pipelined`): if the
+        next batch is on the device already, its forward is started before this call waits.  The buffer has to outlive that
+        (see `promise`)."""
+        if next_out_ptr is None:
+            rc = _lib.load().mdk_gru_forward_staged(self._h, ctypes.c_ulonglong(token), int(B), int(T), out_ptr)
+        else:
+            rc = _lib.load().mdk_gru_forward_pipelined(self._h, ctypes.c_ulonglong(token), int(B), int(T), out_ptr, next_out_ptr)
         if rc == _lib.MDK_ERR_ARG:
             return False
         _lib.check(rc, "mdk_gru_forward_staged")
         return True
+
+    # The result buffer promised to the engine for the next call (it may be written to from now on): kept HERE so that it cannot
+    # be released before the engine has let go of it (close / drop_pending).
+    def promise(self, tensor):
+        self._promised = tensor
+
+    def take_promised(self, shape):
+        """The buffer promised last time if it has this shape (the engine may have filled it already); otherwise the promise is
+        withdrawn -- the engine waits for whatever it started and forgets it -- and None is returned."""
+        t = getattr(self, "_promised", None)
+        self._promised = None
+        if t is None:
+            return None
+        if tuple(t.shape) == tuple(shape):
+            return t
+        self.drop_pending()
+        return None
+
+    def drop_pending(self):
+        if self._h:
+            _lib.check(_lib.load().mdk_gru_drop_pending(self._h), "mdk_gru_drop_pending")
 
     def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
         """Raw-pointer forward: host pointers (`host=True`) or device pointers + hipStream_t."""
@@ -270,7 +297,8 @@ class GruEngine:
         with self._stage_lock:
             h, self._h = self._h, ctypes.c_void_p()
         if h:
-            _lib.load().mdk_gru_destroy(h)
+            _lib.load().mdk_gru_destroy(h)       # (waits for a batch started ahead)
+        self._promised = None
 
     def __del__(self):
         try:

@@ -77,6 +77,8 @@ ABI = {
     "mdk_gru_get_split": (_i, [_vp, ctypes.POINTER(GruSplit)]),
     "mdk_gru_stage_input": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mdk_gru_forward_staged": (_i, [_vp, ctypes.c_ulonglong, _i, _i, _vp]),
+    "mdk_gru_forward_pipelined": (_i, [_vp, ctypes.c_ulonglong, _i, _i, _vp, _vp]),
+    "mdk_gru_drop_pending": (_i, [_vp]),
     "mdk_split_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(SplitShape)]),
     "mdk_margin_sim": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "mdk_pass_plan": (_i, [ctypes.POINTER(GruDesc), _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(PassShape)]),

@@ -113,6 +113,12 @@ class CountsMatrixModel(TorchModel):
             raise ValueError(f"{type(fenc)} is not a valid feature encoder for {clsname}.")
 
 
+def _early_start():
+    """MEDAKA_AMD_EARLY_START=0: `predict_on_batch` never promises the next call's result buffer, so the engine never starts the
+    next batch's forward ahead of its call (include/medaka_amd.h `mdk_gru_forward_pipelined`)."""
+    return os.environ.get("MEDAKA_AMD_EARLY_START", "1").strip().lower() not in ("0", "off", "false")
+
+
 def gpu_share():
     """Processes sharing this process's GPU: `MEDAKA_AMD_PROCS_PER_GPU`, set by `medaka_amd.launch --procs-per-gpu`."""
     try:
@@ -210,9 +216,19 @@ class GRUModel(CountsMatrixModel):
             if x.dim() != 3 or x.shape[2] != self.num_features:
                 raise ValueError(f"expected (B, T, {self.num_features}) input, got {tuple(x.shape)}")
             B, T, _ = x.shape
-            out = _host_output((B, T, 5))
-            if staged is not None and staged[0] is eng and eng.forward_staged(staged[1], B, T, out.data_ptr()):
-                return out                                    # x was already on its way: no PCIe wait in this call
+            # the result buffer: the one promised to the engine at the end of the previous call, if any -- the engine may have
+            # started THIS batch's forward ahead of this call and be streaming its probabilities into it (mdk_gru_forward_pipelined)
+            out = eng.take_promised((B, T, 5))
+            if out is None:
+                out = _host_output((B, T, 5))
+            if staged is not None and staged[0] is eng:
+                nxt = _host_output((B, T, 5)) if _early_start() and out.is_pinned() else None
+                if nxt is not None and not nxt.is_pinned():
+                    nxt = None
+                eng.promise(nxt)
+                if eng.forward_staged(staged[1], B, T, out.data_ptr(), nxt.data_ptr() if nxt is not None else None):
+                    return out                                # x was already on its way: no PCIe wait in this call
+                eng.promise(None)
             eng.forward_ptr(x.data_ptr(), B, T, out.data_ptr(), host=True)
             return out
         return self.forward(x).detach().cpu()

@@ -618,6 +618,76 @@ def test_collated_batches_are_handed_over_early(gold):
         del os.environ["MEDAKA_AMD_STAGE"]
 
 
+@pytest.mark.parametrize("mode", ["split", "sequential", "half"])
+def test_the_next_forward_starts_ahead_of_its_call(gold, mode):
+    """`mdk_gru_forward_pipelined` (what `predict_on_batch` calls for a batch the engine's collate handed over): while a call
+    waits for its last result chunks, the forward of the batch staged behind it is already enqueued in the model's second
+    context, streaming into the buffer promised for it.  Asserted: every result has the bits of a lone call (split scans,
+    sequential scans -- which then run side by side --, half precision), the calls after the first find their work started
+    (`host_streamed` bit 3), and everything that can come between a start and its call -- another entry of the model, a batch of
+    another shape, batches redeemed out of order, an edited tensor, the engine being closed -- ends in the right answer."""
+    class S:
+        def __init__(self, f):
+            self.features = f
+    m = models.GRUModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gold["weights_trained"].items()})
+    m = m.to("cuda").eval()
+    if mode == "half":
+        m.half()
+    eng = m.engine()
+    if mode == "sequential":
+        eng.set_option("scan_split", 0)
+    xs = [synth.counts_windows(24, 4096, depth=40, seed=160 + i) for i in range(6)]
+    want = [eng.forward_host(x).copy() for x in xs]              # lone calls (the first one audited)
+    assert eng.split()["status"] == ("not used" if mode == "sequential" else "certified")
+    collate = lambda x: Batch.collate([S(r) for r in x])
+    # the loader is ahead: six batches staged, redeemed in order
+    bs = [collate(x) for x in xs]
+    started = []
+    for b, w in zip(bs, want):
+        assert np.array_equal(m.predict_on_batch(b).numpy(), w)
+        started.append(bool(eng.timing()["host_streamed"] & 8))
+    assert started == [False] + [True] * 5, started
+    # ... a second time round (the promised buffers are recycled ones now), results kept by the caller stay intact
+    bs = [collate(x) for x in xs]
+    outs = [m.predict_on_batch(b) for b in bs]
+    assert all(np.array_equal(o.numpy(), w) for o, w in zip(outs, want))
+    # another entry of the model between a start and its call: the batch started ahead is forgotten, its token spent
+    b0, b1 = collate(xs[0]), collate(xs[1])
+    assert np.array_equal(m.predict_on_batch(b0).numpy(), want[0])
+    assert np.array_equal(eng.forward_host(xs[3]), want[3])
+    assert np.array_equal(m.predict_on_batch(b1).numpy(), want[1]) and not eng.timing()["host_streamed"] & 8
+    # out of order, and a batch of another shape behind the current one
+    b0, b1 = collate(xs[0]), collate(xs[1])
+    assert np.array_equal(m.predict_on_batch(b1).numpy(), want[1])
+    assert np.array_equal(m.predict_on_batch(b0).numpy(), want[0])
+    short = xs[2][:10]
+    w_short = eng.forward_host(short).copy()
+    b0, bsh, b1 = collate(xs[0]), collate(short), collate(xs[1])
+    assert np.array_equal(m.predict_on_batch(b0).numpy(), want[0])
+    assert np.array_equal(m.predict_on_batch(bsh).numpy(), w_short) and not eng.timing()["host_streamed"] & 8
+    assert np.array_equal(m.predict_on_batch(b1).numpy(), want[1])
+    # an in-place edit of the batch that was started ahead: its token is not redeemed, the call computes what the tensor holds now
+    b0, b1 = collate(xs[0]), collate(xs[1])
+    assert np.array_equal(m.predict_on_batch(b0).numpy(), want[0])
+    b1.counts_matrix.copy_(torch.from_numpy(xs[4]))
+    assert np.array_equal(m.predict_on_batch(b1).numpy(), want[4])
+    # the switch
+    eng.set_option("early_start", 0)
+    bs = [collate(x) for x in xs[:3]]
+    for b, w in zip(bs, want):
+        assert np.array_equal(m.predict_on_batch(b).numpy(), w) and not eng.timing()["host_streamed"] & 8
+    eng.set_option("early_start", 1)
+    # closing the engine with a forward in flight
+    b0, b1 = collate(xs[0]), collate(xs[1])
+    assert np.array_equal(m.predict_on_batch(b0).numpy(), want[0])
+    eng.close()
+    m._engine = None
+    if mode == "sequential":
+        m.engine().set_option("scan_split", 0)
+    assert np.array_equal(m.predict_on_batch(b1).numpy(), want[1])
+
+
 def test_half_mode_16_window_tiles_with_an_odd_tile_count(gold):
     """Regression (found by the split scan's certificate): in half-precision mode 16-window work-groups of a batch
     with an odd number of 8-window tiles ran their surplus lanes on a copy of the last window -- with the fused
