@@ -226,6 +226,7 @@ struct mdk_gru : Ctx {
         std::vector<hipEvent_t> out_done;    // (unused after the enqueue: the stream waits for them itself)
     };
     struct Pending { Started st; unsigned long long token = 0; StageSlot *slot = nullptr; int B = 0, T = 0; float *probs_host = nullptr; } pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> dbg_spans;   // MDK_EARLY_DEBUG: first .. last kernel of every split forward (timing events)
     int opt_early_start = 1;                 // 0: the staged entry never starts the next batch's forward ahead of its call
     long early_started = 0, early_used = 0, early_dropped = 0;
 };
@@ -275,6 +276,23 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     drop_pending(m);
+    if (getenv("MDK_EARLY_DEBUG") && m->dbg_spans.size() > 12) {
+        // the last forwards of the model: duration of each, idle time between one's last kernel and the next one's first
+        (void)hipDeviceSynchronize();
+        const size_t n = m->dbg_spans.size(), lo = n - 12;
+        fprintf(stderr, "[medaka_amd] last split forwards (ms) / gap to the next (ms):");
+        for (size_t i = lo; i < n; ++i) {
+            float d = 0.f, g = 0.f;
+            (void)hipEventElapsedTime(&d, m->dbg_spans[i].first, m->dbg_spans[i].second);
+            if (i + 1 < n) (void)hipEventElapsedTime(&g, m->dbg_spans[i].second, m->dbg_spans[i + 1].first);
+            fprintf(stderr, " %.3f/%.3f", d, g);
+        }
+        fprintf(stderr, "\n");
+    }
+    for (auto &pr : m->dbg_spans) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (getenv("MDK_EARLY_DEBUG"))
+        fprintf(stderr, "[medaka_amd] staged calls %ld: forwards started ahead %ld, taken over %ld, dropped %ld\n", m->staged_used, m->early_started,
+                m->early_used, m->early_dropped);
     for (auto &L : m->layers) {
         free_dev(L.w_ih_t); free_dev(L.w_hh_t); free_dev(L.bias_gi); free_dev(L.b_hn);
         free_dev(L.whh_frag); free_dev(L.ones); free_dev(L.wx_frag); free_dev(L.up_scale_rec); free_dev(L.wih_frag); free_dev(L.inv_scale_rec); free_dev(L.inv_scale_gi);
@@ -1540,6 +1558,13 @@ static int split_enqueue(mdk_gru *m, const SplitPlan &sp, const float *x_dev, fl
     if (rc) return rc;
     *need_gi = P.need_gi;
     if ((rc = ensure_workspace(m, (((size_t)Bv + kTileWin - 1) / kTileWin * kTileWin) * (size_t)sp.Tv, P.need_gi))) return rc;
+    static const bool dbg_spans = getenv("MDK_EARLY_DEBUG") != nullptr;
+    if (dbg_spans) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, s));
+        m->dbg_spans.push_back({a, b});
+    }
     HIP_TRY(hipMemsetAsync(m->split_flag, 0, kSplitFlagWords * sizeof(unsigned), s));
     // Host buffers.  x crosses PCIe whole, one contiguous copy in front of the forward: all of it is needed within the
     // first half of layer 0 (1 ms of work against 1.4 ms of PCIe), so slabs gain nothing -- measured both as DMA slabs and
@@ -1563,6 +1588,7 @@ static int split_enqueue(mdk_gru *m, const SplitPlan &sp, const float *x_dev, fl
     // (no gi, hence no device-side fallback in this pass: the range flag goes home with the certificate)
     if (!P.need_gi) HIP_TRY(hipMemcpyAsync(m->oor_host, m->oor_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(m->kernels_done, s));        // the call's last kernel: the other context's next forward may start behind it
+    if (dbg_spans) HIP_TRY(hipEventRecord(m->dbg_spans.back().second, s));
     for (hipEvent_t e : out_done) HIP_TRY(hipStreamWaitEvent(s, e, 0));
     HIP_TRY(hipGetLastError());
     return MDK_OK;
@@ -1982,7 +2008,9 @@ static int try_early_start(mdk_gru *m, unsigned long long token, int B, int T, f
     if (!m->opt_early_start || !next_probs_host || m->pending.st.valid || m->timing) return MDK_OK;
     // a call that the learner will move (a smaller margin on trial) or that an audit / probe will repeat is not worth starting:
     // its plan is not known before the current call has been judged
-    if (m->opt_scan_split == 1 && m->opt_split_adapt > 0 && m->margin.quiet + 2 >= m->opt_split_adapt) return MDK_OK;
+    const int g_now = m->margin.cur ? m->margin.cur : m->opt_split_margin;
+    if (m->opt_scan_split == 1 && m->opt_split_adapt > 0 && m->margin.quiet + 2 >= m->opt_split_adapt &&
+        split_margin_down(g_now, m->margin.floor_) != 0) return MDK_OK;
     if (m->margin.trial_back) return MDK_OK;
     if (m->opt_scan_split && m->opt_split_audit == 1 &&
         (m->split_audited_key == 0 || (m->opt_split_audit_every > 0 && m->split_calls_since_audit + 2 >= m->opt_split_audit_every))) return MDK_OK;

@@ -25,6 +25,7 @@ ap.add_argument("--batches", type=int, default=24)
 ap.add_argument("--batch", type=int, default=200)
 ap.add_argument("--modes", default="split,sequential")
 ap.add_argument("--precisions", default="fp32,half")
+ap.add_argument("--early", default="0,1")
 args = ap.parse_args()
 B, T = args.batch, 10000
 dev = torch.device("cuda", 0)
@@ -41,7 +42,7 @@ for prec in args.precisions.split(","):
     eng = model.engine()
     for mode in args.modes.split(","):
         eng.set_option("scan_split", 0 if mode == "sequential" else 1)
-        for early in (0, 1):
+        for early in [int(v) for v in args.early.split(",")]:
             eng.set_option("early_start", early)
             bench.fed_loop(model, windows, B, 4, fast, warm=1)
             r = bench.fed_loop(model, windows, B, args.batches, fast)
