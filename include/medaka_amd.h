@@ -146,7 +146,11 @@ int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, f
  * its work in flight or done (mdk_gru_timing.host_streamed bit 3).  Same bits as a lone call.  The buffer must stay valid and
  * untouched until that call has returned, or until mdk_gru_drop_pending / mdk_gru_destroy / any other entry of the model (all of
  * which wait for the batch started ahead and forget it; its token is then spent: mdk_gru_forward answers).  NULL: exactly
- * mdk_gru_forward_staged.  Option "early_start" = 0 (environment MDK_EARLY_START) turns the early start off. */
+ * mdk_gru_forward_staged.  Option "early_start" = 0 (environment MDK_EARLY_START) turns the early start off.
+ * Option "stage_overlap" = 2 | 1 | 0 (environment MDK_STAGE_OVERLAP): a split call started ahead runs its LAYER 0 beside the
+ * previous batch's LAYER 1 -- a layer-0 work-group (8 KB of LDS, a latency chain that leaves the matrix pipe idle most of its
+ * step) shares a CU with a fused layer-1 work-group; layers of the same kind still follow each other (2: both precisions,
+ * 1: half precision only, 0: a batch started ahead waits for the previous batch's last kernel). */
 int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host, float *next_probs_host);
 int mdk_gru_drop_pending(mdk_gru *m);
 

@@ -7,9 +7,3 @@
 Importing this package never touches the GPU and never falls back to a CPU implementation.
 """
 __version__ = "0.1.0"
-import os as _os
-
-# HIP's hardware-queue pool (read when the runtime initialises, at the process's first HIP call): a model's two contexts own
-# eleven streams, and on the default four queues they alias and serialise each other (csrc/api.hip, mdk_default_hw_queues --
-# the library sets the same default when it is loaded; this line also covers a torch that touches the device before that).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -33,16 +33,6 @@ using namespace mdk;
 
 #include "host_common.hpp"
 
-// HIP hands its streams out over a pool of hardware queues (GPU_MAX_HW_QUEUES per priority level, 4 by default), and streams
-// that share a queue are serialised -- a wait for an event in one of them holds up whatever the other put behind it.  A model
-// owns eleven streams (two contexts of five + the staging stream): on four queues the two contexts' side and copy streams
-// alias and two sequential scans that should run side by side run one after the other (149 -> 154 M columns/s; 221 M with 8
-// queues, profiles/r6_experiments/README.md).  The runtime reads the variable when it initialises, i.e. at the process's first
-// HIP call: a default is put into the environment when this library is loaded (an explicit setting wins; a process that has
-// used HIP before loading the library keeps what it started with -- `early_start` then still overlaps a forward with the
-// previous call's result copies, but not two sequential scans with each other).
-__attribute__((constructor)) static void mdk_default_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
 extern "C" const char *mdk_last_error(void) { return g_mdk_err.c_str(); }
 extern "C" const char *mdk_version(void) { return "medaka_amd 0.1 (gfx950)"; }
 
@@ -145,6 +135,9 @@ struct Ctx {
     mdk_gru_timing last{};
     std::vector<hipEvent_t> ev;
     hipEvent_t kernels_done = nullptr;       // behind the last KERNEL of the pass(es) this context enqueued last (its result copies may still run)
+    bool shares_copy_streams = false;        // copy_in / copy_out / copy_out2 belong to the other context (init_ctx)
+    hipEvent_t l0_done = nullptr;            // behind layer 0 of that pass
+    hipEvent_t wait_before_l1 = nullptr;     // this pass: layers >= 1 start behind this event of the OTHER context (stage overlap, start_call)
     int last_wgs = 0;                        // recurrence work-groups (x directions x gpu_share) of that pass: 0 = nothing enqueued yet
 };
 
@@ -228,6 +221,7 @@ struct mdk_gru : Ctx {
     struct Pending { Started st; unsigned long long token = 0; StageSlot *slot = nullptr; int B = 0, T = 0; float *probs_host = nullptr; } pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dbg_spans;   // MDK_EARLY_DEBUG: first .. last kernel of every split forward (timing events)
     int opt_early_start = 1;                 // 0: the staged entry never starts the next batch's forward ahead of its call
+    int opt_stage_overlap = 2;               // a batch started ahead: its layer 0 beside the previous batch's layer 1 (0 off, 1 half precision, 2 both)
     long early_started = 0, early_used = 0, early_dropped = 0;
 };
 
@@ -238,19 +232,26 @@ static void swap_ctx(mdk_gru *m) { std::swap(static_cast<Ctx &>(*m), m->other); 
 // streams and flags of the CURRENT context (create: the first; the second on its first use -- swap, init, swap back)
 static int init_ctx(mdk_gru *m) {
     if (m->stream) return MDK_OK;
-    // The stream the recurrences run on gets a priority of its own: HIP hands its streams out over a small pool of hardware
-    // queues PER PRIORITY (GPU_MAX_HW_QUEUES = 4 by default), and two streams that land on one queue are serialised -- with five
-    // streams per context and two contexts the main streams of both shared a queue, and two sequential scans that should have
-    // run side by side ran one after the other (profiles/r6_experiments/README.md: 149 -> 154 M columns/s with the default pool,
-    // 221 M with 8 queues).  The two main streams are the only high-priority streams of the model: a queue each.
+    // The SECOND context's main stream gets a priority of its own: HIP hands its streams out over a small pool of hardware queues
+    // PER PRIORITY (GPU_MAX_HW_QUEUES = 4 by default) and streams that land on one queue are serialised -- a second main stream
+    // from the same pool could share the first one's queue, and a batch started ahead could then never run its layer 0 beside the
+    // previous batch's layer 1 ("stage_overlap").  As the only high-priority stream of the model it has a queue to itself; the
+    // first context's streams are created exactly as they were before there was a second (a high-priority main stream there
+    // costs the cold host-to-host call 0.15 ms: profiles/r6_experiments/README.md).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+    if (const char *e = getenv("MDK_STREAM_PRIO")) { if (!atoi(e)) prio_hi = prio_lo = 0; }
+    // (the copy streams are shared by the two contexts -- `other` holds them already when the second one is initialised: their
+    // work is DMA behind events, in the order the forwards were enqueued, and every stream less is one hardware queue less to alias)
+    const bool share = m->other.copy_in != nullptr;
+    if (share) { m->copy_in = m->other.copy_in; m->copy_out = m->other.copy_out; m->copy_out2 = m->other.copy_out2; m->shares_copy_streams = true; }
+    if ((share ? hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess ||
         hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->copy_out2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->kernels_done, hipEventDisableTiming) != hipSuccess)
+        (!share && (hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
+                    hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
+                    hipStreamCreateWithFlags(&m->copy_out2, hipStreamNonBlocking) != hipSuccess)) ||
+        hipEventCreateWithFlags(&m->kernels_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->l0_done, hipEventDisableTiming) != hipSuccess)
         return fail(MDK_ERR_DEVICE, "hipStreamCreate failed");
     if (hipMalloc((void **)&m->oor_flag, 8192) != hipSuccess) return fail(MDK_ERR_OOM, "hipMalloc failed");
     (void)hipMemset(m->oor_flag, 0, 8192);
@@ -265,6 +266,8 @@ static void free_ctx(Ctx &c) {
     for (auto e : c.ev) (void)hipEventDestroy(e);
     for (auto e : c.ov_ev) (void)hipEventDestroy(e);
     if (c.kernels_done) (void)hipEventDestroy(c.kernels_done);
+    if (c.l0_done) (void)hipEventDestroy(c.l0_done);
+    if (c.shares_copy_streams) c.copy_in = c.copy_out = c.copy_out2 = nullptr;       // (the other context's)
     for (hipStream_t st : {c.stream, c.side, c.copy_in, c.copy_out, c.copy_out2})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     c = Ctx{};
@@ -299,8 +302,9 @@ extern "C" void mdk_gru_destroy(mdk_gru *m) {
     }
     free_dev(m->wlin_frag);
     free_dev(m->lin_w); free_dev(m->lin_b);
-    free_ctx(static_cast<Ctx &>(*m));
-    free_ctx(m->other);
+    (void)hipDeviceSynchronize();
+    if (m->shares_copy_streams) { free_ctx(static_cast<Ctx &>(*m)); free_ctx(m->other); }
+    else { free_ctx(m->other); free_ctx(static_cast<Ctx &>(*m)); }
     free_dev(m->aux_dev); free_dev(m->x_dev); free_dev(m->audit);
     if (m->stage_stream) { (void)hipStreamSynchronize(m->stage_stream); (void)hipStreamDestroy(m->stage_stream); }
     for (auto &sl : m->stage) { free_dev(sl.dev); if (sl.ready) (void)hipEventDestroy(sl.ready); }
@@ -535,6 +539,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     drop_pending(m);                 // (a batch started ahead was planned under the old options)
     if (!strcmp(key, "early_start")) {
         m->opt_early_start = value ? 1 : 0;
+    } else if (!strcmp(key, "stage_overlap")) {
+        if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "stage_overlap must be 0, 1 (half precision) or 2 (both precisions)");
+        m->opt_stage_overlap = value;
     } else if (!strcmp(key, "rec_windows_per_tile")) {
         if (value != 0 && value != 4 && value != 8 && value != 16)
             return fail(MDK_ERR_ARG, "rec_windows_per_tile must be 0, 4, 8 or 16 (16: half precision only)");
@@ -1220,6 +1227,7 @@ int Pass::layer(int l) {
     const bool side_gemm = P.overlap && l == 0;                    // layer 1's projection behind this layer's chunks
     const bool side_head = (P.overlap || P.stream_out) && l == L - 1 && L >= 2;   // classifier head behind the chunks
     int rc;
+    if (l == 1 && m->wait_before_l1) HIP_TRY(hipStreamWaitEvent(s, m->wait_before_l1, 0));
     if ((rc = tm.begin(SLOT_GI0 + l))) return rc;
     if (fuse) {
         const size_t need = (size_t)P.n_wg * T * kXfragLanes;
@@ -1255,6 +1263,7 @@ int Pass::layer(int l) {
     }
     if ((rc = tm.end_at(rspan))) return rc;
     m->last.rec_launches++;
+    if (l == 0) HIP_TRY(hipEventRecord(m->l0_done, s));
     in = outp;
     return MDK_OK;
 }
@@ -1273,6 +1282,7 @@ int Pass::copy_out() {
         // 37-50 GB/s, profiles/r4_experiments/dma2d_probe.txt) -- DMA, not a copy kernel: any kernel that talks to host memory
         // from the recurrence's CUs stalls it (profiles/r4_experiments/README.md)
         int n_copy = 0;
+        static const bool one_copy_stream = getenv("MDK_ONE_COPY_STREAM") && atoi(getenv("MDK_ONE_COPY_STREAM"));
         for (const OutRange &r : out_ranges) {
             HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
             HIP_TRY(hipStreamWaitEvent(m->copy_out2, r.ready, 0));
@@ -1284,7 +1294,7 @@ int Pass::copy_out() {
                 HIP_TRY(hipMemcpy2DAsync(io->p_host + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
                                          probs + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
                                          (size_t)(b - a) * C * sizeof(float), (size_t)sp->B, hipMemcpyDeviceToHost,
-                                         (n_copy++ & 1) ? m->copy_out2 : m->copy_out));
+                                         ((n_copy++ & 1) && !one_copy_stream) ? m->copy_out2 : m->copy_out));
             }
         }
         for (hipStream_t cs : {m->copy_out, m->copy_out2}) {
@@ -1880,8 +1890,21 @@ static int start_call(mdk_gru *m, const float *x_dev, int B, int T, float *probs
     }
     // two forwards side by side only where both leave the other its CUs (sequential scans of the reference's batch sizes: 100 of
     // 256 CUs each); a recurrence that holds every CU tolerates nothing beside it (profiles/r4_experiments/README.md)
-    if (prev && prev->kernels_done && prev->last_wgs > 0 && (split || wgs + prev->last_wgs > 256))
-        HIP_TRY(hipStreamWaitEvent(s, prev->kernels_done, 0));
+    m->wait_before_l1 = nullptr;
+    if (prev && prev->kernels_done && prev->last_wgs > 0 && (split || wgs + prev->last_wgs > 256)) {
+        // Stage overlap (option "stage_overlap"): this batch's LAYER 0 beside the previous batch's LAYER 1 -- a layer-0 work-group
+        // (8 KB of LDS, a latency chain that leaves the matrix pipe idle two thirds of its step in half precision) fits on a CU
+        // beside a fused layer-1 work-group; layers of the same kind still follow each other
+        static const int env_so = getenv("MDK_STAGE_OVERLAP") ? atoi(getenv("MDK_STAGE_OVERLAP")) : -1;
+        const int so = env_so >= 0 ? env_so : m->opt_stage_overlap;
+        const bool stage = split && m->desc.num_layers == 2 && (so == 2 || (so == 1 && m->precision == MDK_PREC_FP16));
+        if (stage) {
+            HIP_TRY(hipStreamWaitEvent(s, prev->l0_done, 0));
+            m->wait_before_l1 = prev->kernels_done;
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s, prev->kernels_done, 0));
+        }
+    }
     st->split = split;
     st->precision = m->precision;
     if (split) {
@@ -1891,6 +1914,7 @@ static int start_call(mdk_gru *m, const float *x_dev, int B, int T, float *probs
     } else {
         if ((rc = run_passes(m, x_dev, B, T, probs_dev, s, nullptr, probs_host))) return rc;
     }
+    m->wait_before_l1 = nullptr;
     st->valid = true;
     return MDK_OK;
 }
