@@ -228,6 +228,7 @@ class GRUModel(CountsMatrixModel):
                 eng.promise(nxt)
                 if eng.forward_staged(staged[1], B, T, out.data_ptr(), nxt.data_ptr() if nxt is not None else None):
                     return out                                # x was already on its way: no PCIe wait in this call
+                eng.drop_pending()                            # (token no longer valid: nothing may still write to `nxt`)
                 eng.promise(None)
             eng.forward_ptr(x.data_ptr(), B, T, out.data_ptr(), host=True)
             return out

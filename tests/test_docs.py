@@ -85,7 +85,8 @@ def test_cited_evidence_files_exist():
     """Every `profiles/...` path the documents cite is a tracked file (or a glob / brace list that matches some)."""
     import glob
     missing = []
-    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "r5_experiments", "README.md")):
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "r5_experiments", "README.md"),
+                os.path.join("profiles", "r6_experiments", "README.md")):
         text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
         for m in re.finditer(r"profiles/[A-Za-z0-9_./{},*\-]+", text):
             path = m.group(0).rstrip(".,)")

@@ -151,6 +151,9 @@ def test_engine_model_class_inside_the_unmodified_run_prediction(sgold, gold, mo
         def set_normalise(self, n): assert n
         def set_option(self, k, v): pass
         def close(self): pass
+        def take_promised(self, shape): return None        # (no batch is ever started ahead here: nothing was promised)
+        def promise(self, tensor): pass
+        def drop_pending(self): pass
 
         def forward_ptr(self, x_ptr, B, T, out_ptr, stream=None, host=False):
             assert host and stream is None
