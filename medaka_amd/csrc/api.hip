@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2070,6 +2071,7 @@ extern "C" int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, i
     if (!m) return fail(MDK_ERR_ARG, "null model");
     if (!probs_host || token == 0) return fail(MDK_ERR_ARG, "null buffer / token");
     HIP_TRY(hipSetDevice(m->device));
+    const auto t_entry = std::chrono::steady_clock::now();
     mdk_gru::StageSlot *sl = nullptr;
     mdk_gru::Started pre;
     bool from_pending = false;
@@ -2098,11 +2100,22 @@ extern "C" int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, i
         // this call's own first attempt, enqueue only -- so that the next batch's can follow it before anything is waited for
         if (!rc && next_probs_host) rc = start_call(m, sl->dev, B, T, m->p_dev, m->stream, probs_host, &pre, m->other.stream ? &m->other : nullptr);
     }
+    static const bool dbg_t = getenv("MDK_EARLY_DEBUG") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
     if (!rc && pre.valid) rc = try_early_start(m, token, B, T, next_probs_host);
+    const auto t_b = std::chrono::steady_clock::now();
     const long used_before = m->early_used;
     if (!rc) rc = run_forward(m, sl->dev, B, T, m->p_dev, m->stream, nullptr, probs_host, &pre);
+    const auto t_c = std::chrono::steady_clock::now();
     if (rc) (void)hipDeviceSynchronize();
     else if (hipStreamSynchronize(m->stream) != hipSuccess) rc = fail(MDK_ERR_DEVICE, "hipStreamSynchronize failed");
+    if (dbg_t) {
+        const auto t_d = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        if (ms(t_entry, t_d) > 8.0)
+            fprintf(stderr, "[medaka_amd] slow staged call: own enqueue %.2f ms, next batch's enqueue %.2f ms, run_forward (wait + certificate) %.2f ms, "
+                            "final synchronize %.2f ms\n", ms(t_entry, t_a), ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+    }
     release_slot(m, sl);
     m->staged_used++;
     m->last.host_streamed |= 4;
