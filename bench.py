@@ -260,6 +260,8 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
         for prob in class_probs:
             write_row(prob)
     predict_ms, wait_ms, hand_ms, futures, t_start, done = [], [], [], [], None, 0
+    ahead_of = getattr(model, "_engine", None) if hasattr(getattr(model, "_engine", None), "timing") and hasattr(model, "gru") else None
+    started_ahead = [0]
     while True:
         t0 = time.perf_counter()
         item = batches_q.get()
@@ -269,6 +271,8 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
         t1 = time.perf_counter()
         class_probs = model.predict_on_batch(batch)
         t2 = time.perf_counter()
+        if ahead_of is not None and ahead_of.timing()["host_streamed"] & 8:      # this batch's forward had been enqueued ahead of its call
+            started_ahead[0] += done >= warm
         if per_sample_submit:
             for sample, prob in zip(data, class_probs):
                 futures.append(writer.submit(write_row, prob))
@@ -303,6 +307,7 @@ def fed_loop(model, windows, batch_size, n_batches, collate, warm=2, cache=8, sa
             "main_thread_wait_for_batch_ms_median": statistics.median(wait_ms[warm:]),
             "main_thread_hand_to_writer_ms_median": statistics.median(hand_ms[warm:]),
             "writer_submits_per_batch": batch_size if per_sample_submit else 1,
+            "forwards_started_ahead": started_ahead[0],       # timed batches whose forward the previous call had already enqueued (mdk_gru_forward_pipelined)
             **({"predict_ms_all": [round(v, 3) for v in predict_ms], "wait_ms_all": [round(v, 3) for v in wait_ms],
                 "collate_ms_all": [round(v, 3) for v in collate_ms]} if detail else {})}
 
@@ -645,6 +650,7 @@ def summary_of(result):
            "first_calls_ms": g(result, "host_to_host", "first_calls_ms"),
            "fed_loop": g(result, "fed_loop", "value", scale=M), "pcie_diet": g(result, "pcie_diet_columns_per_s", scale=M),
            "fed_loop_predict_ms": g(result, "fed_loop", "engine_collate", "predict_ms_median", nd=2),
+           "fed_loop_started_ahead": g(result, "fed_loop", "engine_collate", "forwards_started_ahead"),
            "sequential_scan": g(result, "sequential_scan", "value", scale=M),
            "sequential_fed_loop": g(result, "sequential_fed_loop", "value", scale=M),
            "scan_split": {k: (float(f"{sp[k]:.3g}") if isinstance(sp.get(k), float) else sp.get(k)) for k in ("chunks", "margin", "status", "max_delta")},
