@@ -417,7 +417,7 @@ def kernel_table(timing_lists, fused_layers, split, B, T, half, traffic_families
                     e["hbm_measured_gb"] = rec["hbm_bytes_per_step"] / 1e9
     return k, step
 
-def pmc_summary_r4(name="r5_pmc_step.csv"):
+def pmc_summary_r4(name="r6_pmc_step.csv"):
     """Matrix-pipe busy share and HBM rate per kernel family from the committed counter summary of THIS build at 200 x 10000
     (profiles/r5_pmc_step.csv: rocprofv3 --pmc passes of `bench.py --device-only --steps 1`, summed over the step by
     profiles/pmc_step.py).  SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs."""
