@@ -2102,7 +2102,15 @@ extern "C" int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, i
     }
     static const bool dbg_t = getenv("MDK_EARLY_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
-    if (!rc && pre.valid) rc = try_early_start(m, token, B, T, next_probs_host);
+    // (a batch that cannot be started ahead -- no memory for the second context, say -- is no reason to fail THIS call: the
+    // early start is switched off for the model and the batch takes the ordinary way when its call comes)
+    auto start_next = [&]() {
+        if (try_early_start(m, token, B, T, next_probs_host) != MDK_OK) {
+            fprintf(stderr, "[medaka_amd] the next batch's forward could not be started ahead (%s): early start off for this model\n", g_mdk_err.c_str());
+            m->opt_early_start = 0;
+        }
+    };
+    if (!rc && pre.valid) start_next();
     const auto t_b = std::chrono::steady_clock::now();
     const long used_before = m->early_used;
     if (!rc) rc = run_forward(m, sl->dev, B, T, m->p_dev, m->stream, nullptr, probs_host, &pre);
@@ -2121,7 +2129,7 @@ extern "C" int mdk_gru_forward_pipelined(mdk_gru *m, unsigned long long token, i
     m->last.host_streamed |= 4;
     if (from_pending && m->early_used != used_before) m->last.host_streamed |= 8;
     // the batch behind this one may have landed only now: its forward then runs under whatever the caller does between two calls
-    if (!rc) rc = try_early_start(m, token, B, T, next_probs_host);
+    if (!rc) start_next();
     return rc;
 }
 
