@@ -93,6 +93,28 @@ def test_counts_entry_checks_its_arguments_before_any_device_call():
             call(eng, counts, depth, probs=False, decoded=True, out=bad)
 
 
+def test_pipelined_entry_checks_its_arguments_and_the_promise_queue():
+    """`mdk_gru_forward_pipelined` / `mdk_gru_drop_pending`: null model, null buffer and token 0 are refused before any device
+    call; the Python side of the promise (`GruEngine.promise / take_promised`): a buffer of another shape withdraws the promise
+    and tells the engine to forget what it started."""
+    import ctypes
+    import types
+    from medaka_amd import engine, lib
+    L = lib.load()
+    buf = (ctypes.c_float * 4)()
+    assert L.mdk_gru_forward_pipelined(None, 1, 1, 4, buf, None) == lib.MDK_ERR_ARG and "null model" in lib.last_error()
+    assert L.mdk_gru_drop_pending(None) == lib.MDK_ERR_ARG
+    dropped = []
+    eng = types.SimpleNamespace(_promised=None, drop_pending=lambda: dropped.append(1))
+    take = lambda shape: engine.GruEngine.take_promised(eng, shape)
+    assert take((2, 3, 5)) is None and not dropped                      # nothing promised: nothing to withdraw
+    t = types.SimpleNamespace(shape=(2, 3, 5))
+    engine.GruEngine.promise(eng, t)
+    assert take((2, 3, 5)) is t and eng._promised is None and not dropped
+    engine.GruEngine.promise(eng, t)
+    assert take((4, 3, 5)) is None and dropped == [1] and eng._promised is None
+
+
 def test_grumodel_mirrors_reference_interface():
     m = models.GRUModel(num_features=10, num_classes=5, gru_size=128)
     # state_dict keys are the stock nn.GRU / nn.Linear names (SURVEY 3.2)
