@@ -14,7 +14,7 @@ LIB = os.environ.get("MDK_LIB_OUT") or os.path.join(HERE, "libmedaka_amd.so")
 LIB_DEBUG = os.path.join(HERE, "libmedaka_amd_debug.so")
 SOURCES = ["api.hip", "rl_api.hip"]
 HEADERS = ["common.hpp", "layout.hpp", "host_common.hpp", "rec_mfma.hpp", "rec_fused.hpp", "gi_proj.hpp", "head.hpp", "exact.hpp",
-           "rl_front.hpp", "lstm_wide.hpp", "scan_split.hpp",
+           "rl_front.hpp", "lstm_wide.hpp", "scan_split.hpp", "gru_model.hpp", "gru_pass.hpp", "gru_split.hpp", "gru_entries.hpp",
            os.path.join("..", "..", "include", "medaka_amd.h")]
 
 
