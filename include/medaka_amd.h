@@ -236,6 +236,10 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
+ *   "early_start"          = 1 | 0                  mdk_gru_forward_pipelined: enqueue the next staged batch's forward before waiting for
+ *                                                   the current one (see that entry; environment MDK_EARLY_START)
+ *   "stage_overlap"        = 2 | 1 | 0              ... and run its layer 0 beside the current batch's layer 1 (2: both precisions, 1: half
+ *                                                   precision only, 0: whole forwards follow each other; environment MDK_STAGE_OVERLAP)
  *   "stream_host"          = 1 | 0                  mdk_gru_forward, sequential scan: copy x in / probabilities out in time
  *                                                   slabs under the recurrences (0: one copy before, one after).  A split
  *                                                   call copies x in once (all of it is needed at once) and sends the

@@ -205,7 +205,6 @@ static int init_ctx(mdk_gru *m) {
     // costs the cold host-to-host call 0.15 ms: profiles/r6_experiments/README.md).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (const char *e = getenv("MDK_STREAM_PRIO")) { if (!atoi(e)) prio_hi = prio_lo = 0; }
     // (the copy streams are shared by the two contexts -- `other` holds them already when the second one is initialised: their
     // work is DMA behind events, in the order the forwards were enqueued, and every stream less is one hardware queue less to alias)
     const bool share = m->other.copy_in != nullptr;

@@ -654,7 +654,6 @@ int Pass::copy_out() {
         // 37-50 GB/s, profiles/r4_experiments/dma2d_probe.txt) -- DMA, not a copy kernel: any kernel that talks to host memory
         // from the recurrence's CUs stalls it (profiles/r4_experiments/README.md)
         int n_copy = 0;
-        static const bool one_copy_stream = getenv("MDK_ONE_COPY_STREAM") && atoi(getenv("MDK_ONE_COPY_STREAM"));
         for (const OutRange &r : out_ranges) {
             HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
             HIP_TRY(hipStreamWaitEvent(m->copy_out2, r.ready, 0));
@@ -666,7 +665,7 @@ int Pass::copy_out() {
                 HIP_TRY(hipMemcpy2DAsync(io->p_host + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
                                          probs + (size_t)a * C, (size_t)sp->T * C * sizeof(float),
                                          (size_t)(b - a) * C * sizeof(float), (size_t)sp->B, hipMemcpyDeviceToHost,
-                                         ((n_copy++ & 1) && !one_copy_stream) ? m->copy_out2 : m->copy_out));
+                                         (n_copy++ & 1) ? m->copy_out2 : m->copy_out));
             }
         }
         for (hipStream_t cs : {m->copy_out, m->copy_out2}) {
