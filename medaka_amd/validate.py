@@ -1,7 +1,7 @@
 """python -m medaka_amd.validate <model.tar.gz | weights.npz> -- what does THIS model do on the engine?
 
 Every published consensus model is a git-LFS stub where this engine was built, so the split scan's margin, the
-certificate's behaviour and the three rates were measured on weights trained in the build container.  This is the one
+certificate's behaviour and the rates (device-resident, host to host, fed loop) were measured on weights trained in the build container.  This is the one
 command that answers the same questions for a real archive on the first box that has one (reference `options.py:11-14`,
 `datastore.py:135-157`):
 
@@ -129,6 +129,35 @@ def _rate(fn, sync, steps=5, warmup=2):
     return (time.perf_counter() - t0) / steps
 
 
+def _fed_loop(model, eng, x, n_batches=24, ahead=4):
+    """A loader thread collating `ahead` batches in front of the main thread's predict_on_batch calls."""
+    import queue
+    import threading
+    from medaka_amd.torch_ext import Batch
+
+    class _S:
+        def __init__(self, f):
+            self.features = f
+    rows = [np.ascontiguousarray(r) for r in x]
+    q = queue.Queue(maxsize=ahead)
+
+    def loader():
+        for _ in range(n_batches + 2):
+            q.put(Batch.collate([_S(r) for r in rows]))
+    t = threading.Thread(target=loader, daemon=True)
+    t.start()
+    started, t0 = 0, None
+    for i in range(n_batches + 2):
+        model.predict_on_batch(q.get())
+        if i == 1:
+            t0 = time.perf_counter()                 # (two warm-up batches)
+        elif i > 1:
+            started += bool(eng.timing()["host_streamed"] & 8)
+    dt = (time.perf_counter() - t0) / n_batches
+    t.join()
+    return {"columns_per_s": x.shape[0] * x.shape[1] / dt, "ms_per_batch": 1e3 * dt, "batches": n_batches, "forwards_started_ahead": started}
+
+
 def run(model, cpu, B, T, depth, half, sample_windows, log=_log):
     """One precision: margin table, learned margin, certificate per input structure, parity sample, rates."""
     import torch
@@ -187,8 +216,15 @@ def run(model, cpu, B, T, depth, half, sample_windows, log=_log):
         model.predict_on_batch(xb)
     dth = _rate(lambda: model.predict_on_batch(xb), lambda: None, steps=7, warmup=0)
     res["host_to_host"] = {"columns_per_s": B * T / dth, "ms_per_batch": 1e3 * dth}
+    # ... and the loop the reference runs (prediction.py:44-52, 225-370): a loader thread collates batches ahead (every batch is on
+    # its way to the device when it is made), the main thread calls predict_on_batch -- which also starts the NEXT batch's forward
+    # before it returns (include/medaka_amd.h mdk_gru_forward_pipelined)
+    res["fed_loop"] = _fed_loop(model, eng, x, n_batches=24)
+    if half:
+        res["learned"]["fp32_parity_probes"] = eng.split().get("probes")        # half precision: margins are used only after an fp32-parity probe
     log(f"  settled at margin {learned['margin']} ({learned['status']}); {B * T / dt / 1e6:.1f} M columns/s device-resident, "
-        f"{B * T / dth / 1e6:.1f} M host to host, sequential scan {B * T / dts / 1e6:.1f} M")
+        f"{B * T / dth / 1e6:.1f} M host to host, {res['fed_loop']['columns_per_s'] / 1e6:.1f} M fed loop "
+        f"({res['fed_loop']['forwards_started_ahead']} of {res['fed_loop']['batches']} forwards started ahead), sequential scan {B * T / dts / 1e6:.1f} M")
     # ---- per input structure: certificate and parity against PyTorch-CPU on a sample of windows
     kinds = {}
     for kind in ("iid",) + tuple(synth.STRUCTURED_KINDS):
@@ -222,7 +258,7 @@ def main(argv=None):
     if args.plan_only:
         model, _, desc = load_model(args.model, torch.device("cpu"))
         report = {"model": describe(model, desc, B, T), "plan_only": True,
-                  "checks": ["margin table " + str(list(MARGINS)), "learned margin over 16 calls", "rates: device-resident, sequential, host to host",
+                  "checks": ["margin table " + str(list(MARGINS)), "learned margin over 16 calls", "rates: device-resident, sequential, host to host, fed loop",
                              "inputs: iid + " + ", ".join(__import__("medaka_amd.synth", fromlist=["x"]).STRUCTURED_KINDS)]}
     else:
         if not torch.cuda.is_available():
