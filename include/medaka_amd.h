@@ -67,7 +67,8 @@ typedef struct {
     int rec_launches;     /* recurrence launches in the last forward */
     int n_layers;
     int host_streamed;    /* split calls through mdk_gru_forward: bit 1 = the probabilities left in column chunks under the
-                             second half of the last layer's scan (option "stream_host"; else one copy after the forward); bit 2 = x had
+                             second half of the last layer's scan (option "stream_host"; else one copy after the forward; bit 5: the last of them by
+                             kernel, "tail_blit"); bit 2 = x had
                              been handed over early (mdk_gru_forward_staged: no PCIe wait for the input inside the call); bit 3 = the
                              forward itself had been enqueued ahead of the call (mdk_gru_forward_pipelined) */
     int fused_layers;     /* bit l set: layer l ran with its input projection fused into the recurrence (option
@@ -236,6 +237,9 @@ int mdk_gru_set_normalise(mdk_gru *m, int normalise);
  *                                                   mdk_gru_split.audits / audit_failures / audit_worst_dp count them
  *   "scan_split_margin"    = 128 | multiple of 8 in 16..4096   (environment MDK_SCAN_SPLIT / MDK_SCAN_SPLIT_MARGIN, read
  *                                                   when a model is created, set the defaults of these two options)
+ *   "tail_blit"            = 1 | 0                  mdk_gru_forward with a page-locked result buffer: the result chunks of a split call's last
+ *                                                   two launches are written home by a kernel behind the last recurrence instead of queueing
+ *                                                   behind the DMA copies of the earlier ones (environment MDK_TAIL_BLIT)
  *   "early_start"          = 1 | 0                  mdk_gru_forward_pipelined: enqueue the next staged batch's forward before waiting for
  *                                                   the current one (see that entry; environment MDK_EARLY_START)
  *   "stage_overlap"        = 2 | 1 | 0              ... and run its layer 0 beside the current batch's layer 1 (2: both precisions, 1: half

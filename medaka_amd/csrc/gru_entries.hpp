@@ -228,8 +228,21 @@ extern "C" int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, fl
     const size_t nx = (size_t)B * T * m->desc.num_features, np = (size_t)B * T * m->desc.num_classes;
     int rc = ensure_staging(m, nx, np);
     if (rc) return rc;
+    // a page-locked result buffer is visible to the device: the last chunks of a split call's result may then leave by kernel
+    // behind the last recurrence (Pass::copy_out, k_tail_to_host) -- here only: no other forward runs behind a cold call
+    m->tail_host = m->tail_dev = nullptr;
+    if (m->opt_tail_blit) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, probs_host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+            m->tail_host = probs_host;
+            m->tail_dev = static_cast<float *>(at.devicePointer);
+        } else {
+            (void)hipGetLastError();       // pageable memory: not an error, the DMA queue takes every chunk
+        }
+    }
     // x streams in and the probabilities stream out while the recurrences run (forward_pass, HostIO)
     rc = run_forward(m, m->x_dev, B, T, m->p_dev, m->stream, x_host, probs_host);
+    m->tail_host = m->tail_dev = nullptr;
     if (rc) { (void)hipDeviceSynchronize(); return rc; }   // nothing of ours may still touch the caller's buffers
     HIP_TRY(hipStreamSynchronize(m->stream));
     return MDK_OK;

@@ -185,6 +185,8 @@ struct mdk_gru : Ctx {
     };
     struct Pending { Started st; unsigned long long token = 0; StageSlot *slot = nullptr; int B = 0, T = 0; float *probs_host = nullptr; } pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> dbg_spans;   // MDK_EARLY_DEBUG: first .. last kernel of every split forward (timing events)
+    int opt_tail_blit = 1;                   // mdk_gru_forward, page-locked result buffer: the last result chunks of a split call leave by kernel
+    float *tail_host = nullptr, *tail_dev = nullptr;   // ... the buffer of the call in progress and the device's view of it (else null)
     int opt_early_start = 1;                 // 0: the staged entry never starts the next batch's forward ahead of its call
     int opt_stage_overlap = 2;               // a batch started ahead: its layer 0 beside the previous batch's layer 1 (0 off, 1 half precision, 2 both)
     long early_started = 0, early_used = 0, early_dropped = 0;
@@ -333,6 +335,7 @@ extern "C" int mdk_gru_create(const mdk_gru_desc *desc, const float *const *weig
     if (const char *e = getenv("MDK_SCAN_SPLIT_ADAPT")) m->opt_split_adapt = std::max(atoi(e), 0);
     if (const char *e = getenv("MDK_SCAN_SPLIT_PROBE")) m->opt_split_probe = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_EARLY_START")) m->opt_early_start = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("MDK_TAIL_BLIT")) m->opt_tail_blit = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MDK_SCAN_SPLIT_MARGIN")) {
         const int g = atoi(e);
         if (g >= 16 && g <= 4096 && g % 8 == 0) m->opt_split_margin = g;
@@ -501,7 +504,9 @@ extern "C" int mdk_gru_set_option(mdk_gru *m, const char *key, int value) {
     if (!m || !key) return fail(MDK_ERR_ARG, "null argument");
     (void)hipSetDevice(m->device);
     drop_pending(m);                 // (a batch started ahead was planned under the old options)
-    if (!strcmp(key, "early_start")) {
+    if (!strcmp(key, "tail_blit")) {
+        m->opt_tail_blit = value ? 1 : 0;
+    } else if (!strcmp(key, "early_start")) {
         m->opt_early_start = value ? 1 : 0;
     } else if (!strcmp(key, "stage_overlap")) {
         if (value < 0 || value > 2) return fail(MDK_ERR_ARG, "stage_overlap must be 0, 1 (half precision) or 2 (both precisions)");

@@ -75,6 +75,8 @@ enum { SLOT_GI0 = 0, SLOT_REC0 = 4, SLOT_HEAD = 8 };
 struct HostIO {
     const float *x_host = nullptr;   // (nb, T, F) of this pass, or null: x is already on the device
     float *p_host = nullptr;         // (nb, T, C) of this pass, or null: probabilities stay on the device
+    float *p_host_dev = nullptr;     // the device's view of p_host where the caller's buffer is page-locked AND no other forward will run
+                                     // behind this one (the cold host entry): the last result chunks then leave by kernel (k_tail_to_host)
 };
 
 // the streamed host path of a split call cuts the last layer's scan into launches (forward_pass): only for virtual windows
@@ -215,7 +217,7 @@ struct Pass {
     const SplitPlan *sp;
     std::vector<hipEvent_t> *join_later;     // split call: the events behind its last result copies (run_split waits for them
                                              // after its certificate kernel) instead of a wait on `s`
-    struct OutRange { hipEvent_t ready; int t0, nt; };
+    struct OutRange { hipEvent_t ready; int t0, nt; int launch; };
     std::vector<OutRange> out_ranges;        // column ranges to copy out; issued after every launch is enqueued, because a
                                              // copy into pageable memory may block the calling thread until it is done
     const float *in = nullptr;               // input of the current layer
@@ -472,8 +474,8 @@ int Pass::layer_final_head(int l, const LayerDev &Ld, float *outp) {
         if ((rc = pool_event(m, &ev))) return rc;
         HIP_TRY(hipEventRecord(ev, s));
         const int lo0 = T - ph[p + 1], hi0 = ph[p], len = ph[p + 1] - ph[p];
-        if (lo0 + len == hi0) out_ranges.push_back({ev, lo0, 2 * len});
-        else { out_ranges.push_back({ev, lo0, len}); out_ranges.push_back({ev, hi0, len}); }
+        if (lo0 + len == hi0) out_ranges.push_back({ev, lo0, 2 * len, (int)p});
+        else { out_ranges.push_back({ev, lo0, len, (int)p}); out_ranges.push_back({ev, hi0, len, (int)p}); }
     }
     m->last.rec_launches--;   // (the caller counts the layer once)
     head_done = true;
@@ -556,8 +558,8 @@ int Pass::layer_phased(int l, const LayerDev &Ld, float *outp, bool fuse, bool s
                 hipEvent_t hv;
                 if ((rc = pool_event(m, &hv))) return rc;
                 HIP_TRY(hipEventRecord(hv, m->side));
-                if (lo0 + len == hi0) out_ranges.push_back({hv, lo0, 2 * len});
-                else { out_ranges.push_back({hv, lo0, len}); out_ranges.push_back({hv, hi0, len}); }
+                if (lo0 + len == hi0) out_ranges.push_back({hv, lo0, 2 * len, p});
+                else { out_ranges.push_back({hv, lo0, len, p}); out_ranges.push_back({hv, hi0, len, p}); }
             }
         }
     }
@@ -653,8 +655,21 @@ int Pass::copy_out() {
         // [t0, t0 + nt)): they leave for the caller's buffer behind the launch's event as 2-D DMA copies (B rows of a few KB:
         // 37-50 GB/s, profiles/r4_experiments/dma2d_probe.txt) -- DMA, not a copy kernel: any kernel that talks to host memory
         // from the recurrence's CUs stalls it (profiles/r4_experiments/README.md)
+        // The ranges of the LAST TWO launches do not go to the DMA queue where the CUs can take them (HostIO::p_host_dev): the
+        // queue is still behind when the scan ends -- in half precision by 0.45 ms -- and a kernel behind the last recurrence
+        // writes them home at the full PCIe rate while the queue finishes what it has (k_tail_to_host).
+        TailRanges tail{};
+        const int last_launch = out_ranges.empty() ? 0 : out_ranges.back().launch;
         int n_copy = 0;
         for (const OutRange &r : out_ranges) {
+            // (half precision only: in fp32-parity mode the scan is slow enough for the queue to keep up, and the kernel would only
+            // add its own 0.1 ms behind the last recurrence -- measured 7.95 -> 8.05 ms; half precision 5.74 -> 5.58 ms)
+            // (two launches: one 5.68, two 5.57, three 5.76, four 6.2 ms per half-precision call -- what the kernel takes it takes
+            // AFTER the scan, what the queue takes it takes under it)
+            if (io->p_host_dev && P.hp && r.launch + 2 > last_launch && tail.n < 4 && out_ranges.size() > 4) {
+                tail.t0[tail.n] = r.t0; tail.nt[tail.n] = r.nt; tail.n++;
+                continue;
+            }
             HIP_TRY(hipStreamWaitEvent(m->copy_out, r.ready, 0));
             HIP_TRY(hipStreamWaitEvent(m->copy_out2, r.ready, 0));
             for (int k = 0; k < sp->S; ++k) {
@@ -667,6 +682,11 @@ int Pass::copy_out() {
                                          (size_t)(b - a) * C * sizeof(float), (size_t)sp->B, hipMemcpyDeviceToHost,
                                          (n_copy++ & 1) ? m->copy_out2 : m->copy_out));
             }
+        }
+        if (tail.n) {
+            hipLaunchKernelGGL(k_tail_to_host, dim3((unsigned)sp->B, (unsigned)(tail.n * sp->S)), dim3(256), 0, s, (const float *)probs,
+                               io->p_host_dev, *sp, tail, C);
+            m->last.host_streamed |= 32;
         }
         for (hipStream_t cs : {m->copy_out, m->copy_out2}) {
             hipEvent_t done;

@@ -129,6 +129,7 @@ static int split_enqueue(mdk_gru *m, const SplitPlan &sp, const float *x_dev, fl
     if (!m->oor_host) HIP_TRY(hipHostMalloc((void **)&m->oor_host, sizeof(int), hipHostMallocDefault));
     HostIO io;
     io.p_host = probs_host;
+    if (probs_host && probs_host == m->tail_host) io.p_host_dev = m->tail_dev;      // (the cold host entry: the last chunks may leave by kernel)
     PassPlan P;                    // this call synchronises for its certificate anyway: it looks at the range flag itself
     int rc = plan_pass(m, Bv, sp.Tv, probs_host ? &io : nullptr, &sp, P, /*host_checks_range=*/true);
     if (rc) return rc;

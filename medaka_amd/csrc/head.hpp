@@ -266,4 +266,22 @@ static __global__ __launch_bounds__(256) void k_decode(const float *__restrict__
     pmax[i] = bv;
 }
 
+// The last result chunks of a split host call, written to the caller's (page-locked, device-visible) buffer by the CUs.
+// The scan's second half produces probabilities about as fast as one DMA queue ships them as 2-D copies (half precision:
+// 40 MB in 1.1 ms), so when the last recurrence kernel ends the copies of its last launches are still queued: 0.45 ms of
+// tail on a 5.7 ms call (profiles/r6_experiments/README.md section 1).  At that moment the CUs have nothing to do -- a copy
+// kernel that talks to host memory BESIDE a recurrence stalls it (profiles/r4_experiments/README.md), behind the last one it
+// stalls nothing -- and a kernel writes pinned host memory at the full PCIe rate (54 GB/s, profiles/r2_host_path_probe.txt).
+// Block (w, j): window w, range r = j / S of chunk k = j % S: the real columns core_k /\ (start[k] + [t0[r], t0[r] + nt[r])).
+struct TailRanges { int n; int t0[4]; int nt[4]; };
+static __global__ __launch_bounds__(256) void k_tail_to_host(const float *__restrict__ probs, float *__restrict__ host, SplitPlan sp,
+                                                             TailRanges tr, int C) {
+    const int w = blockIdx.x, r = blockIdx.y / sp.S, k = blockIdx.y % sp.S;
+    const int a = max(sp.core0[k], sp.start[k] + tr.t0[r]), b = min(sp.core0[k + 1], sp.start[k] + tr.t0[r] + tr.nt[r]);
+    if (a >= b) return;
+    const size_t base = ((size_t)w * sp.T + a) * C;
+    const int n = (b - a) * C;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) host[base + i] = probs[base + i];
+}
+
 }  // namespace mdk
