@@ -134,7 +134,7 @@ int mdk_gru_forward(mdk_gru *m, const float *x_host, int B, int T, float *probs_
  * for a truly asynchronous copy) on a stream of its own and returns at once with a token.  mdk_gru_forward_staged(token,
  * ...) later answers exactly like mdk_gru_forward(x_host, ...) without waiting for PCIe: the 1.4 ms an 80 MB batch
  * takes to cross overlap the previous batch's forward.  x_host must stay untouched until the staged forward returns.
- * Twelve batches can be staged ahead (the reference's loader keeps up to 8 in its queue); a token that was pushed out (or never redeemed) makes mdk_gru_forward_staged
+ * Ten batches can be staged (the reference's loader keeps up to 8 in its queue, one is being read by the forward, one may have been started ahead); a token that was pushed out (or never redeemed) makes mdk_gru_forward_staged
  * return MDK_ERR_ARG -- call mdk_gru_forward instead.  Callable from another thread than the forwards. */
 int mdk_gru_stage_input(mdk_gru *m, const float *x_host, int B, int T, unsigned long long *token);
 int mdk_gru_forward_staged(mdk_gru *m, unsigned long long token, int B, int T, float *probs_host);
