@@ -211,7 +211,9 @@ static int init_ctx(mdk_gru *m) {
     // work is DMA behind events, in the order the forwards were enqueued, and every stream less is one hardware queue less to alias)
     const bool share = m->other.copy_in != nullptr;
     if (share) { m->copy_in = m->other.copy_in; m->copy_out = m->other.copy_out; m->copy_out2 = m->other.copy_out2; m->shares_copy_streams = true; }
-    if ((share ? hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess ||
+    // (a runtime without stream priorities: an ordinary stream -- stage overlap may then find the two main streams on one queue)
+    if (share && hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { (void)hipGetLastError(); m->stream = nullptr; }
+    if ((!m->stream && hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
         (!share && (hipStreamCreateWithFlags(&m->copy_in, hipStreamNonBlocking) != hipSuccess ||
                     hipStreamCreateWithFlags(&m->copy_out, hipStreamNonBlocking) != hipSuccess ||
