@@ -70,4 +70,21 @@ if has pmc; then
   python profiles/pmc_step.py "$OUT/pmc" "$OUT/pmc_step.csv" "$OUT/traffic.json" > /dev/null
   find "$OUT/pmc" -name "*.csv" -size +2M -delete
 fi
+if has pmc_half; then
+  cd /tmp
+  i=0
+  for PASS in \
+    "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+    "FETCH_SIZE" \
+    "WRITE_SIZE" ; do
+    i=$((i+1))
+    # (MDK_SCAN_SPLIT_PROBE=0: the one forward of the process is the half-precision one, not its fp32-parity probe in front of it)
+    MDK_SCAN_SPLIT_PROBE=0 timeout 200 rocprofv3 --pmc $PASS --output-format csv -d "$OUT/pmc_half/pass$i" -o pmc -- \
+        python "$R/bench.py" --half --device-only --steps 1 --warmup 0 > "$OUT/pmc_half_pass$i.log" 2>&1
+    echo "pmc half pass $i ($PASS) rc=$?"
+  done
+  cd "$R"
+  python profiles/pmc_step.py "$OUT/pmc_half" "$OUT/pmc_step_half.csv" "$OUT/traffic_half.json" > /dev/null
+  find "$OUT/pmc_half" -name "*.csv" -size +2M -delete
+fi
 ls -la "$OUT"
