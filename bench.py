@@ -94,7 +94,7 @@ def parse():
                          "off by default -- the larger workspace it allocates hands the old one back to the driver")
     ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"),
                     help="where the complete record goes (stdout carries only the compact line the driver parses)")
-    ap.add_argument("--loop-batches", type=int, default=14,
+    ap.add_argument("--loop-batches", type=int, default=32,
                     help="batches of the fed loop (threaded loader -> collate -> predict_on_batch -> writer; 0 = skip)")
     return ap.parse_args()
 
@@ -331,7 +331,7 @@ def loop_report(model, B, T, depth, seed, n_batches, host_to_host_rate=None):
            "batch_windows": B, "chunk_len": T}
     fast = lambda data: torch_ext.Batch.collate(data)
     for name, fn in (("reference_collate", reference_collate), ("engine_collate", fast)):
-        fed_loop(model, windows, B, 3, fn, warm=1)                     # allocator warm-up (page-locked blocks)
+        fed_loop(model, windows, B, 14, fn, warm=1)                    # allocator warm-up: the loader runs 8 batches ahead, every one a page-locked block
         out[name] = fed_loop(model, windows, B, n_batches, fn)
         log(f"fed loop, {name}: {out[name]['value'] / 1e6:.1f} M columns/s, collate {out[name]['collate_ms_median']:.2f} ms, "
             f"predict {out[name]['predict_ms_median']:.2f} ms per batch")
@@ -1046,7 +1046,7 @@ def main():
         from medaka_amd import torch_ext
         windows = loop_windows(T, args.depth, 4321 + ranks.rank)
         fast = lambda data: torch_ext.Batch.collate(data)
-        fed_loop(model, windows, B, 3, fast, warm=1)
+        fed_loop(model, windows, B, 14, fast, warm=1)
         ranks.barrier()
         mine_loop = fed_loop(model, windows, B, args.loop_batches, fast)
         shared_loop = {"value": ranks.sum_over_ranks(mine_loop["value"]), "unit": "pileup columns/s", "processes": ranks.world,
@@ -1148,7 +1148,7 @@ def main():
             from medaka_amd import torch_ext
             windows = loop_windows(T, args.depth, 4321)
             fast = lambda data: torch_ext.Batch.collate(data)
-            fed_loop(model, windows, B, 3, fast, warm=1)
+            fed_loop(model, windows, B, 14, fast, warm=1)
             sl = fed_loop(model, windows, B, max(8, args.loop_batches // 2), fast)
             result["sequential_fed_loop"] = {k: sl[k] for k in ("value", "unit", "ms_per_batch", "timed_batches", "predict_ms_median",
                                                                 "main_thread_cycle_ms_median", "steady_state_value")}
