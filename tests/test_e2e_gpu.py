@@ -326,6 +326,10 @@ def test_validate_tool_on_a_state_dict(gold, tmp_path):
         assert r["margin_table_iid"][128]["status"] == "certified" and r["smallest_certified_margin"] in (64, 96, 128), r["margin_table_iid"]
         assert r["learned"]["status"] == "certified" and r["learned"]["settled_at"] in (64, 96, 128)
         assert r["device_resident"]["columns_per_s"] > r["sequential_scan"]["columns_per_s"] > 0 and r["host_to_host"]["columns_per_s"] > 0
+        # the loop the reference runs: a loader thread ahead of predict_on_batch, whose forwards are then started ahead of their calls
+        assert r["fed_loop"]["columns_per_s"] > 0 and r["fed_loop"]["forwards_started_ahead"] >= r["fed_loop"]["batches"] // 2, r["fed_loop"]
+        if prec == "half":
+            assert r["learned"]["fp32_parity_probes"] >= 1, r["learned"]
         for kind, k in r["inputs"].items():
             assert k["status"] in ("certified", "rejected", "disabled", "not used")
             assert k["max_abs_dp_vs_cpu"] <= tol and k["argmax_identical"] >= 0.999 * k["columns_checked"], (prec, kind, k)
